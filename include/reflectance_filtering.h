@@ -1,0 +1,105 @@
+/*
+ * reflectance_filtering.h -- C ABI of librf_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the three native calls on the reference's hot path.
+ * Every entry point takes plain device pointers and sizes, runs asynchronously
+ * on the HIP stream it is given (hipStream_t passed as void*; NULL = the null
+ * stream), never allocates or synchronises on the launch path once its
+ * parameter tables are cached, and never throws: it returns RF_OK or a negative
+ * RF_E* code, and rf_last_error() returns the calling thread's message.
+ *
+ * There is no CPU fallback in this library.  Images are uint8, interleaved
+ * (H x W x C), tightly packed, batched along the leading dimension n; every
+ * image of a batch is filtered independently (no inter-image or inter-GPU
+ * traffic; shard batches across GPUs by giving each process its own slice).
+ */
+#ifndef REFLECTANCE_FILTERING_H
+#define REFLECTANCE_FILTERING_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RF_VERSION 100 /* 0.1.0 */
+
+/* return codes */
+#define RF_OK 0
+#define RF_E_BADARG (-1)      /* NULL pointer, non-positive size, sigma handling is OpenCV's (<=0 -> 1) */
+#define RF_E_UNSUPPORTED (-2) /* channel count / radius / border outside what is implemented */
+#define RF_E_WORKSPACE (-3)   /* workspace too small for one image */
+#define RF_E_HIP (-4)         /* a HIP runtime call failed; see rf_last_error() */
+
+/* border types, numerically equal to cv::BorderTypes */
+#define RF_BORDER_CONSTANT 0
+#define RF_BORDER_REPLICATE 1
+#define RF_BORDER_REFLECT 2
+#define RF_BORDER_WRAP 3
+#define RF_BORDER_REFLECT_101 4
+#define RF_BORDER_DEFAULT RF_BORDER_REFLECT_101
+
+/* rf_jbf_u8 flags */
+#define RF_JBF_TRUE_DIVISION 1 /* dst = sum / wsum; default is OpenCV's sum * (1.f / wsum) */
+#define RF_JBF_FORCE_GENERIC 2 /* use the untiled global-memory kernel (debug / cross-check) */
+
+int rf_version(void);
+const char *rf_last_error(void);
+/* Frees the per-device parameter tables (colour LUTs, tap tables). */
+int rf_shutdown(void);
+
+/*
+ * Joint bilateral filter, 8-bit.
+ * Replaces  cv2.ximgproc.jointBilateralFilter(joint, src, d, sigmaColor, sigmaSpace[, borderType])
+ * as called at /root/reference/filter_reflectance.py:60-64 (d = -1).
+ *   joint  n*h*w*joint_cn   device, joint_cn in {1,3}
+ *   src    n*h*w*src_cn     device, src_cn   in {1,3}
+ *   dst    n*h*w*src_cn     device, must not alias joint or src
+ *   d <= 0 -> radius = cvRound(1.5*sigma_space), else radius = d/2; radius >= 1
+ * Per pixel the taps are accumulated in OpenCV's order (row-major over the
+ * disk, float32, separately rounded multiply and add), so the uint8 result is
+ * bit-identical to the restated CPU algorithm.
+ */
+int rf_jbf_u8(const uint8_t *joint, const uint8_t *src, uint8_t *dst, int n, int h, int w,
+              int joint_cn, int src_cn, int d, double sigma_color, double sigma_space, int border,
+              int flags, void *stream);
+
+/*
+ * Guided filter, 8-bit, colour guide.
+ * Replaces  cv2.ximgproc.guidedFilter(guide, src, radius, eps)  as called at
+ * /root/reference/filter_reflectance.py:67-70 (radius = int(sigma_spatial), eps = sigma_color).
+ *   guide  n*h*w*3        device (guide_cn must be 3: cv2.imread always yields 3 channels)
+ *   src    n*h*w*src_cn   device, src_cn in {1,3}
+ *   dst    n*h*w*src_cn   device; may alias src
+ *   iterations >= 1: the filter is applied `iterations` times with the same guide, the uint8
+ *   result of one pass being the src of the next (the reference's "3x GF" chain of CLI runs).
+ *   workspace: device scratch of at least rf_gf_workspace_bytes(1, ...) bytes; larger
+ *   workspaces let more images of the batch be in flight at once.
+ */
+size_t rf_gf_workspace_bytes(int n, int h, int w, int guide_cn, int src_cn, int radius);
+int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, int n, int h, int w,
+             int guide_cn, int src_cn, int radius, double eps, int iterations, void *workspace,
+             size_t workspace_bytes, void *stream);
+
+/*
+ * 1x1 CNN reflectance predictor on uint8 BGR images.
+ * Replaces  caffe.Net(network_definition.prototxt, TEST, weights=learned_weights.caffemodel),
+ * blobs['images'] <- imgCV2_to_caffeBlob(image), forward(), blobs['reflectance_intensity']
+ * (/root/reference/decompose_with_trained_CNN.py:57-69, 82-95, 100-106).
+ *   bgr        n*h*w*3 uint8 device (cv2.imread layout)
+ *   r_out      n*h*w float32 device or NULL: sigmoid output in (0,1)
+ *   r_u8_out   n*h*w uint8 device or NULL: trunc(r*255), the bytes of `<base>-r.png`
+ *              (/root/reference/image_utils.py:63-68)
+ *   weights    4513 float32 on the device:
+ *              W0[32][3] b0[32] | 4 x (W[32][32] b[32]) | wf[160] bf[1]
+ *   srgb_lut   256 float32 on the device: linear value of each sRGB byte
+ */
+#define RF_CNN_NPARAMS 4513
+int rf_cnn_reflectance_u8(const uint8_t *bgr, float *r_out, uint8_t *r_u8_out, int n, int h, int w,
+                          const float *weights, const float *srgb_lut, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REFLECTANCE_FILTERING_H */

@@ -1,0 +1,82 @@
+"""ctypes binding of librf_hip.so -- the only way the Python host code reaches the GPU.
+
+The C ABI is declared in include/reflectance_filtering.h.  PyTorch is used purely as the
+device-buffer container (allocation, H2D/D2H copies, the current HIP stream); no torch op
+computes anything on the path.  There is NO CPU fallback: if the library is missing, cannot
+be loaded, or no GPU is visible, every entry point raises.
+"""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librf_hip.so")
+
+RF_OK, RF_E_BADARG, RF_E_UNSUPPORTED, RF_E_WORKSPACE, RF_E_HIP = 0, -1, -2, -3, -4
+BORDER_CONSTANT, BORDER_REPLICATE, BORDER_REFLECT, BORDER_WRAP, BORDER_REFLECT_101 = range(5)
+BORDER_DEFAULT = BORDER_REFLECT_101
+JBF_TRUE_DIVISION = 1
+JBF_FORCE_GENERIC = 2
+CNN_NPARAMS = 4513
+
+EXPORTS = ("rf_version", "rf_last_error", "rf_shutdown", "rf_jbf_u8", "rf_gf_workspace_bytes",
+           "rf_gf_u8", "rf_cnn_reflectance_u8")
+
+_lib = None
+_lock = threading.Lock()
+
+
+class RFError(RuntimeError):
+    """A librf_hip.so entry point returned a negative code."""
+
+
+def load_library():
+    """dlopen librf_hip.so and declare the prototypes.  Raises if it was not built."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RFError("%s not found: build it with `python -c 'import __graft_entry__ as g; "
+                          "g.build()'` or `make -C reflectance_filtering_amd/csrc` "
+                          "(there is no CPU fallback)" % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        vp, ci, cd, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_size_t
+        lib.rf_version.argtypes = []
+        lib.rf_version.restype = ci
+        lib.rf_last_error.argtypes = []
+        lib.rf_last_error.restype = ctypes.c_char_p
+        lib.rf_shutdown.argtypes = []
+        lib.rf_shutdown.restype = ci
+        lib.rf_jbf_u8.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, cd, cd, ci, ci, vp]
+        lib.rf_jbf_u8.restype = ci
+        lib.rf_gf_workspace_bytes.argtypes = [ci, ci, ci, ci, ci, ci]
+        lib.rf_gf_workspace_bytes.restype = sz
+        lib.rf_gf_u8.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, cd, ci, vp, sz, vp]
+        lib.rf_gf_u8.restype = ci
+        lib.rf_cnn_reflectance_u8.argtypes = [vp, vp, vp, ci, ci, ci, vp, vp, vp]
+        lib.rf_cnn_reflectance_u8.restype = ci
+        _lib = lib
+        return lib
+
+
+def check(rc, what):
+    if rc == RF_OK:
+        return
+    msg = load_library().rf_last_error().decode("utf-8", "replace")
+    if rc in (RF_E_BADARG, RF_E_UNSUPPORTED):
+        raise ValueError("%s: %s" % (what, msg))
+    raise RFError("%s failed (%d): %s" % (what, rc, msg))
+
+
+def require_gpu():
+    """torch with a visible HIP device, or a loud failure (never a silent CPU path)."""
+    import torch
+    if not torch.cuda.is_available():
+        raise RFError("no HIP device visible: reflectance_filtering_amd runs on MI355X only "
+                      "and has no CPU fallback")
+    return torch
+
+
+def current_stream_ptr(torch):
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

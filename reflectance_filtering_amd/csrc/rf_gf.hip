@@ -1,0 +1,434 @@
+// rf_gf.hip -- colour guided filter, uint8, for gfx950 (MI355X).
+//
+// Replaces cv2.ximgproc.guidedFilter(guide, src, radius, eps) as called at
+// /root/reference/filter_reflectance.py:67-70.  Arithmetic contract (DESIGN.md "GF"): the
+// operation order of opencv_contrib/modules/ximgproc/src/guided_filter.cpp (3-channel guide)
+// over cv::boxFilter(CV_32F, normalize, BORDER_REFLECT) whose sums are double:
+//
+//   stage 1  box means of I_g, I_g*I_g', p_s, p_s*I_g.  Inputs are integers <= 65025, so the
+//            double running sums OpenCV forms are exact integers; we form the same integers
+//            with uint32 arithmetic (any order is exact) and round once:
+//            mean = (float)((double)S * (1.0/k^2)).                         -> gf_stage1_kernel
+//            The per-pixel algebra up to alpha/beta is fused behind it.
+//   stage 2  box means of the float planes alpha_{s,g}, beta_s.  Not exact in double, so the
+//            summation ORDER matters: RowSum<float,double> is a running sum along the
+//            border-extended row starting at its left end, ColumnSum<double,float> a running
+//            sum down the image starting 2r rows above the first output row.  Both are
+//            reproduced as sequential chains (one lane per row / per column), exposed to the
+//            GPU as parallelism over rows x planes x images.  -> gf_rowsum_kernel, gf_colsum_apply_kernel
+#include "rf_common.hpp"
+
+namespace rf {
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// stage 1 + per-pixel algebra
+// ------------------------------------------------------------------------------------------
+constexpr int kAThreads = 256;
+constexpr int kACols = 2;                      // columns per thread
+constexpr int kACW = kAThreads * kACols;       // strip width incl. halo
+constexpr int kAWaves = kAThreads / 64;
+
+template <int SCN>
+struct Quant {
+    static constexpr int NQ = 9 + 4 * SCN;
+    // q: 0..2 I_g | 3..8 I_aI_b (00 01 02 11 12 22) | 9.. p_s | then p_s*I_g (s major)
+    __device__ static inline void eval(const uint8_t *g, const uint8_t *p, uint32_t *v)
+    {
+        const uint32_t g0 = g[0], g1 = g[1], g2 = g[2];
+        v[0] = g0;
+        v[1] = g1;
+        v[2] = g2;
+        v[3] = g0 * g0;
+        v[4] = g0 * g1;
+        v[5] = g0 * g2;
+        v[6] = g1 * g1;
+        v[7] = g1 * g2;
+        v[8] = g2 * g2;
+#pragma unroll
+        for (int s = 0; s < SCN; s++) {
+            const uint32_t ps = p[s];
+            v[9 + s] = ps;
+            v[9 + SCN + 3 * s + 0] = ps * g0;
+            v[9 + SCN + 3 * s + 1] = ps * g1;
+            v[9 + SCN + 3 * s + 2] = ps * g2;
+        }
+    }
+};
+
+__device__ inline float mean_of(uint32_t s, double scale) { return (float)((double)s * scale); }
+
+// index into the 6-entry symmetric store: (0,0)=0 (0,1)=1 (0,2)=2 (1,1)=3 (1,2)=4 (2,2)=5
+__device__ constexpr int sym(int i, int j)
+{
+    return i <= j ? (i * 3 - i * (i - 1) / 2 + (j - i)) : (j * 3 - j * (j - 1) / 2 + (i - j));
+}
+
+// grid: (strips, row segments, images).  ab: [img][SCN*4][h][w] float (g<3 alpha, g=3 beta)
+template <int SCN>
+__global__ __launch_bounds__(kAThreads) void gf_stage1_kernel(
+    const uint8_t *__restrict__ guide, const uint8_t *__restrict__ src, float *__restrict__ ab,
+    int h, int w, int radius, float eps_f, int eps_small, int seg_rows)
+{
+    constexpr int NQ = Quant<SCN>::NQ;
+    __shared__ uint32_t pfx[NQ][kACW + 1];
+    __shared__ uint32_t wave_tot[NQ][kAWaves];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int out_w = kACW - 2 * radius;
+    const int xs = blockIdx.x * out_w;
+    const int ys = blockIdx.y * seg_rows;
+    const int ye = min(ys + seg_rows, h);
+    const size_t npx = (size_t)h * w;
+    const uint8_t *gimg = guide + (size_t)blockIdx.z * npx * 3;
+    const uint8_t *simg = src + (size_t)blockIdx.z * npx * SCN;
+    float *abimg = ab + (size_t)blockIdx.z * npx * (SCN * 4);
+    const int ks = 2 * radius + 1;
+    const double scale = 1.0 / (double)(ks * ks);
+
+    int gx[kACols];
+#pragma unroll
+    for (int k = 0; k < kACols; k++)
+        gx[k] = border_interpolate(xs - radius + tid * kACols + k, w, RF_BORDER_REFLECT);
+
+    uint32_t V[kACols][NQ];
+#pragma unroll
+    for (int k = 0; k < kACols; k++)
+#pragma unroll
+        for (int q = 0; q < NQ; q++)
+            V[k][q] = 0;
+
+    auto add_row = [&](int yy, bool add) {
+        const int gy = border_interpolate(yy, h, RF_BORDER_REFLECT);
+#pragma unroll
+        for (int k = 0; k < kACols; k++) {
+            uint32_t v[NQ];
+            const size_t pix = (size_t)gy * w + gx[k];
+            Quant<SCN>::eval(gimg + pix * 3, simg + pix * SCN, v);
+#pragma unroll
+            for (int q = 0; q < NQ; q++)
+                V[k][q] = add ? V[k][q] + v[q] : V[k][q] - v[q];
+        }
+    };
+
+    for (int yy = ys - radius; yy < ys + radius; yy++)
+        add_row(yy, true);
+    if (tid == 0)
+#pragma unroll
+        for (int q = 0; q < NQ; q++)
+            pfx[q][0] = 0;
+
+    for (int y = ys; y < ye; y++) {
+        add_row(y + radius, true);
+        // inclusive prefix over the strip's columns, per quantity
+        uint32_t incl[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            uint32_t s = V[0][q] + V[1][q];
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t nb = __shfl_up(s, off);
+                if (lane >= off)
+                    s += nb;
+            }
+            incl[q] = s;
+            if (lane == 63)
+                wave_tot[q][wave] = s;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            uint32_t base = 0;
+            for (int wv = 0; wv < wave; wv++)
+                base += wave_tot[q][wv];
+            const uint32_t p1 = incl[q] + base;
+            pfx[q][tid * kACols + 2] = p1;
+            pfx[q][tid * kACols + 1] = p1 - V[1][q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kACols; k++) {
+            const int c = tid * kACols + k;
+            const int x = xs - radius + c;
+            if (c < radius || c >= kACW - radius || x >= w)
+                continue;
+            float m[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; q++)
+                m[q] = mean_of(pfx[q][c + radius + 1] - pfx[q][c - radius], scale);
+            const float *mI = m;
+            float cov[6];
+            // cov(c1,c2) = mean(I1*I2) - mean1*mean2 ; diagonal: - (mean*mean + (-eps))
+            cov[sym(0, 1)] = __fsub_rn(m[4], __fmul_rn(mI[0], mI[1]));
+            cov[sym(0, 2)] = __fsub_rn(m[5], __fmul_rn(mI[0], mI[2]));
+            cov[sym(1, 2)] = __fsub_rn(m[7], __fmul_rn(mI[1], mI[2]));
+            cov[sym(0, 0)] = __fsub_rn(m[3], __fadd_rn(__fmul_rn(mI[0], mI[0]), -eps_f));
+            cov[sym(1, 1)] = __fsub_rn(m[6], __fadd_rn(__fmul_rn(mI[1], mI[1]), -eps_f));
+            cov[sym(2, 2)] = __fsub_rn(m[8], __fadd_rn(__fmul_rn(mI[2], mI[2]), -eps_f));
+            float inv[6];
+#pragma unroll
+            for (int kk = 0; kk < 3; kk++)
+#pragma unroll
+                for (int l = 0; l <= kk; l++) {
+                    const float a00 = cov[sym((kk + 1) % 3, (l + 1) % 3)];
+                    const float a01 = cov[sym((kk + 1) % 3, (l + 2) % 3)];
+                    const float a10 = cov[sym((kk + 2) % 3, (l + 1) % 3)];
+                    const float a11 = cov[sym((kk + 2) % 3, (l + 2) % 3)];
+                    inv[sym(kk, l)] = __fsub_rn(__fmul_rn(a00, a11), __fmul_rn(a01, a10));
+                }
+            float det = __fmul_rn(cov[sym(0, 0)], inv[sym(0, 0)]);
+            det = __fadd_rn(det, __fmul_rn(cov[sym(1, 0)], inv[sym(1, 0)]));
+            det = __fadd_rn(det, __fmul_rn(cov[sym(2, 0)], inv[sym(2, 0)]));
+            if (eps_small && fabsf(det) < 1e-6f)
+                det = 1.f;
+#pragma unroll
+            for (int e = 0; e < 6; e++)
+                inv[e] = __fdiv_rn(inv[e], det);
+            const size_t pix = (size_t)y * w + x;
+#pragma unroll
+            for (int s = 0; s < SCN; s++) {
+                const float mp = m[9 + s];
+                float cp[3];
+#pragma unroll
+                for (int g = 0; g < 3; g++)
+                    cp[g] = __fsub_rn(m[9 + SCN + 3 * s + g], __fmul_rn(mp, mI[g]));
+                float beta = mp;
+#pragma unroll
+                for (int g = 0; g < 3; g++) {
+                    float a = __fmul_rn(inv[sym(g, 0)], cp[0]);
+                    a = __fadd_rn(a, __fmul_rn(inv[sym(g, 1)], cp[1]));
+                    a = __fadd_rn(a, __fmul_rn(inv[sym(g, 2)], cp[2]));
+                    abimg[(size_t)(s * 4 + g) * npx + pix] = a;
+                    beta = __fsub_rn(beta, __fmul_rn(a, mI[g]));
+                }
+                abimg[(size_t)(s * 4 + 3) * npx + pix] = beta;
+            }
+        }
+        add_row(y - radius, false);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// stage 2a: RowSum<float,double>.  One wave = 64 rows of one plane, one lane per row, walking
+// the border-extended row left to right; tiles are transposed through LDS so that global
+// loads/stores stay row-contiguous.
+// ------------------------------------------------------------------------------------------
+constexpr int kBRows = 64;
+constexpr int kBChunk = 32;
+
+__global__ __launch_bounds__(64) void gf_rowsum_kernel(const float *__restrict__ planes,
+                                                       double *__restrict__ rowsums, int h, int w,
+                                                       int radius, int row_blocks)
+{
+    __shared__ float t_in[kBRows][kBChunk + 1];
+    __shared__ float t_out_lo[kBRows][kBChunk + 1];  // leaving values
+    __shared__ double t_d[kBRows][kBChunk + 1];
+
+    const int lane = threadIdx.x;
+    const int plane = blockIdx.x / row_blocks;  // plane index across the whole chunk of images
+    const int row0 = (blockIdx.x - plane * row_blocks) * kBRows;
+    const float *S = planes + (size_t)plane * h * w;
+    double *D = rowsums + (size_t)plane * h * w;
+    const int ks = 2 * radius + 1;
+    const int my_row = min(row0 + lane, h - 1);
+    const int sub = lane >> 5, col = lane & 31;  // loader role: 2 rows x 32 columns per instruction
+
+    double s = 0.0;
+    // prologue: s = sum_{i<ks} ext[i], ext[i] = S[bi(i - r)]
+    for (int i0 = 0; i0 < ks; i0 += kBChunk) {
+        const int xi = i0 + col;
+        const int sx = border_interpolate(min(xi, ks - 1) - radius, w, RF_BORDER_REFLECT);
+        for (int rr = 0; rr < kBRows; rr += 2) {
+            const int row = min(row0 + rr + sub, h - 1);
+            t_in[rr + sub][col] = S[(size_t)row * w + sx];
+        }
+        __syncthreads();
+        const int cnt = min(kBChunk, ks - i0);
+        for (int c = 0; c < cnt; c++)
+            s += (double)t_in[lane][c];
+        __syncthreads();
+    }
+    // D[0] = s; then D[o] for o = 1..w-1:  s += (double)ext[o-1+ks] - (double)ext[o-1]
+    // chunk over o in [1, w): entering S[bi(o + r)], leaving S[bi(o - 1 - r)]
+    for (int o0 = 0; o0 < w; o0 += kBChunk) {
+        const int o = o0 + col;
+        const int se = border_interpolate(min(o, w - 1) + radius, w, RF_BORDER_REFLECT);
+        const int sl = border_interpolate(min(o, w - 1) - 1 - radius, w, RF_BORDER_REFLECT);
+        for (int rr = 0; rr < kBRows; rr += 2) {
+            const int row = min(row0 + rr + sub, h - 1);
+            t_in[rr + sub][col] = S[(size_t)row * w + se];
+            t_out_lo[rr + sub][col] = S[(size_t)row * w + sl];
+        }
+        __syncthreads();
+        const int cnt = min(kBChunk, w - o0);
+        for (int c = 0; c < cnt; c++) {
+            if (o0 + c > 0)
+                s += (double)t_in[lane][c] - (double)t_out_lo[lane][c];
+            t_d[lane][c] = s;
+        }
+        __syncthreads();
+        if (o < w)
+            for (int rr = 0; rr < kBRows; rr += 2) {
+                const int row = row0 + rr + sub;
+                if (row < h)
+                    D[(size_t)row * w + o] = t_d[rr + sub][col];
+            }
+        __syncthreads();
+    }
+    (void)my_row;
+}
+
+// ------------------------------------------------------------------------------------------
+// stage 2b: ColumnSum<double,float> + ApplyTransform + convertTo(uint8).
+// block = 64 columns x (4*SCN) planes; every thread walks its column of one plane from the
+// top of the image; per output row the 4 means of a src channel meet in LDS and the beta
+// thread of that channel forms q = beta + a0*I0 + a1*I1 + a2*I2 and stores the byte.
+// ------------------------------------------------------------------------------------------
+template <int SCN>
+__global__ __launch_bounds__(64 * 4 * SCN) void gf_colsum_apply_kernel(
+    const double *__restrict__ rowsums, const uint8_t *__restrict__ guide,
+    uint8_t *__restrict__ dst, int h, int w, int radius)
+{
+    constexpr int NP = 4 * SCN;
+    constexpr int kDepth = 4;
+    __shared__ float means[2][NP][64];
+
+    const int lane = threadIdx.x;
+    const int plane = threadIdx.y;
+    const int x = blockIdx.x * 64 + lane;
+    const int xc = min(x, w - 1);
+    const size_t npx = (size_t)h * w;
+    const double *R = rowsums + ((size_t)blockIdx.z * NP + plane) * npx + xc;
+    const uint8_t *gimg = guide + (size_t)blockIdx.z * npx * 3;
+    uint8_t *dimg = dst + (size_t)blockIdx.z * npx * SCN;
+    const int ks = 2 * radius + 1;
+    const double scale = 1.0 / (double)(ks * ks);
+
+    double SUM = 0.0;
+    for (int yy = -radius; yy < radius; yy++)
+        SUM += R[(size_t)border_interpolate(yy, h, RF_BORDER_REFLECT) * w];
+
+    for (int y0 = 0; y0 < h; y0 += kDepth) {
+        double sp[kDepth], sm[kDepth];
+#pragma unroll
+        for (int k = 0; k < kDepth; k++) {
+            const int y = min(y0 + k, h - 1);
+            sp[k] = R[(size_t)border_interpolate(y + radius, h, RF_BORDER_REFLECT) * w];
+            sm[k] = R[(size_t)border_interpolate(y - radius, h, RF_BORDER_REFLECT) * w];
+        }
+#pragma unroll
+        for (int k = 0; k < kDepth; k++) {
+            const int y = y0 + k;
+            if (y >= h)
+                break;
+            const double s0 = SUM + sp[k];
+            means[y & 1][plane][lane] = (float)(s0 * scale);
+            SUM = s0 - sm[k];
+            __syncthreads();
+            if ((plane & 3) == 3 && x < w) {
+                const int s = plane >> 2;
+                const size_t pix = (size_t)y * w + x;
+                float q = means[y & 1][plane][lane];
+#pragma unroll
+                for (int g = 0; g < 3; g++)
+                    q = __fadd_rn(q, __fmul_rn(means[y & 1][s * 4 + g][lane],
+                                               (float)gimg[pix * 3 + g]));
+                dimg[pix * SCN + s] = saturate_u8(q);
+            }
+        }
+    }
+}
+
+}  // namespace
+}  // namespace rf
+
+extern "C" size_t rf_gf_workspace_bytes(int n, int h, int w, int guide_cn, int src_cn, int radius)
+{
+    (void)guide_cn;
+    (void)radius;
+    if (n <= 0 || h <= 0 || w <= 0 || (src_cn != 1 && src_cn != 3))
+        return 0;
+    const size_t per_img = (size_t)h * w * (4 * src_cn) * (sizeof(float) + sizeof(double));
+    // enough images in flight to fill the chip, capped at 16 GiB of scratch
+    size_t imgs = (size_t)n;
+    const size_t cap = (size_t)16 << 30;
+    if (imgs * per_img > cap)
+        imgs = cap / per_img;
+    if (imgs < 1)
+        imgs = 1;
+    return imgs * per_img;
+}
+
+extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, int n, int h,
+                        int w, int guide_cn, int src_cn, int radius, double eps, int iterations,
+                        void *workspace, size_t workspace_bytes, void *stream_)
+{
+    using namespace rf;
+    if (!guide || !src || !dst || !workspace)
+        return fail(RF_E_BADARG, "rf_gf_u8: NULL pointer");
+    if (n < 0 || h <= 0 || w <= 0 || iterations < 1)
+        return fail(RF_E_BADARG, "rf_gf_u8: bad size n=%d h=%d w=%d iterations=%d", n, h, w,
+                    iterations);
+    if (guide_cn != 3)
+        return fail(RF_E_UNSUPPORTED, "rf_gf_u8: guide must have 3 channels (got %d)", guide_cn);
+    if (src_cn != 1 && src_cn != 3)
+        return fail(RF_E_UNSUPPORTED, "rf_gf_u8: src channels must be 1 or 3 (got %d)", src_cn);
+    // uint32 window sums: (2r+1)^2 * 255^2 must stay below 2^32; strip width must hold the halo
+    if (radius < 0 || radius > 120)
+        return fail(RF_E_UNSUPPORTED, "rf_gf_u8: radius %d outside 0..120", radius);
+    if (dst == guide)
+        return fail(RF_E_BADARG, "rf_gf_u8: dst must not alias guide");
+    if (n == 0)
+        return RF_OK;
+    const int np = 4 * src_cn;
+    const size_t npx = (size_t)h * w;
+    const size_t per_img = npx * np * (sizeof(float) + sizeof(double));
+    if (workspace_bytes < per_img)
+        return fail(RF_E_WORKSPACE, "rf_gf_u8: workspace %zu B < %zu B needed per image",
+                    workspace_bytes, per_img);
+    hipStream_t stream = (hipStream_t)stream_;
+    int chunk = (int)std::min<size_t>((size_t)n, workspace_bytes / per_img);
+    if (chunk > 65535)
+        chunk = 65535;
+    const float eps_f = (float)eps;
+    const int eps_small = eps < 1e-2;
+    const int out_w = kACW - 2 * radius;
+    const int strips = ceil_div(w, out_w);
+
+    for (int i0 = 0; i0 < n; i0 += chunk) {
+        const int m = std::min(chunk, n - i0);
+        double *rows = reinterpret_cast<double *>(workspace);
+        float *ab = reinterpret_cast<float *>(rows + (size_t)m * np * npx);
+        const uint8_t *g0 = guide + (size_t)i0 * npx * 3;
+        uint8_t *d0 = dst + (size_t)i0 * npx * src_cn;
+        // row segments: enough workgroups to fill 256 CUs, but segments no shorter than 2r+1
+        int seg_rows = h;
+        while ((long long)strips * ceil_div(h, seg_rows) * m < 1024 && seg_rows > 2 * (2 * radius + 1) &&
+               seg_rows > 32)
+            seg_rows = (seg_rows + 1) / 2;
+        const int segs = ceil_div(h, seg_rows);
+        for (int it = 0; it < iterations; it++) {
+            const uint8_t *s0 = (it == 0 ? src : (const uint8_t *)dst) + (size_t)i0 * npx * src_cn;
+            dim3 ga(strips, segs, m);
+            if (src_cn == 3)
+                hipLaunchKernelGGL(gf_stage1_kernel<3>, ga, dim3(kAThreads), 0, stream, g0, s0, ab,
+                                   h, w, radius, eps_f, eps_small, seg_rows);
+            else
+                hipLaunchKernelGGL(gf_stage1_kernel<1>, ga, dim3(kAThreads), 0, stream, g0, s0, ab,
+                                   h, w, radius, eps_f, eps_small, seg_rows);
+            const int row_blocks = ceil_div(h, kBRows);
+            hipLaunchKernelGGL(gf_rowsum_kernel, dim3((unsigned)(m * np * row_blocks)), dim3(64), 0,
+                               stream, ab, rows, h, w, radius, row_blocks);
+            dim3 gc(ceil_div(w, 64), 1, m);
+            if (src_cn == 3)
+                hipLaunchKernelGGL(gf_colsum_apply_kernel<3>, gc, dim3(64, 12), 0, stream, rows, g0,
+                                   d0, h, w, radius);
+            else
+                hipLaunchKernelGGL(gf_colsum_apply_kernel<1>, gc, dim3(64, 4), 0, stream, rows, g0,
+                                   d0, h, w, radius);
+        }
+    }
+    RF_HIP_CHECK(hipGetLastError());
+    return RF_OK;
+}

@@ -1,0 +1,105 @@
+"""Batched device operators: thin, torch-tensor-in / torch-tensor-out wrappers over the C ABI.
+
+All tensors are CUDA(HIP) uint8, contiguous, shaped [N,H,W,C] (C in {1,3}) like a stack of
+``cv2.imread`` results.  Work is enqueued on torch's current stream; nothing synchronises.
+"""
+import numpy as np
+
+from . import _ffi
+
+_gf_workspaces = {}
+_cnn_consts = {}
+
+
+def _chk_images(t, name, torch):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.uint8
+            and t.dim() == 4 and t.is_contiguous()):
+        raise ValueError("%s must be a contiguous CUDA uint8 tensor [N,H,W,C]" % name)
+
+
+def joint_bilateral_u8(joint, src, d, sigma_color, sigma_space, border=_ffi.BORDER_DEFAULT,
+                       flags=0, out=None):
+    """Batched cv2.ximgproc.jointBilateralFilter(joint, src, d, sigmaColor, sigmaSpace)."""
+    torch = _ffi.require_gpu()
+    lib = _ffi.load_library()
+    _chk_images(joint, "joint", torch)
+    _chk_images(src, "src", torch)
+    if joint.shape[:3] != src.shape[:3]:
+        raise ValueError("joint and src must have the same N,H,W")
+    if out is None:
+        out = torch.empty_like(src)
+    n, h, w, scn = src.shape
+    rc = lib.rf_jbf_u8(joint.data_ptr(), src.data_ptr(), out.data_ptr(), n, h, w,
+                       joint.shape[3], scn, int(d), float(sigma_color), float(sigma_space),
+                       int(border), int(flags), _ffi.current_stream_ptr(torch))
+    _ffi.check(rc, "rf_jbf_u8")
+    return out
+
+
+def gf_workspace(n, h, w, scn, radius, device, torch):
+    lib = _ffi.load_library()
+    need = lib.rf_gf_workspace_bytes(n, h, w, 3, scn, radius)
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    ws = _gf_workspaces.get(key)
+    if ws is None or ws.numel() < need:
+        _gf_workspaces.pop(key, None)
+        ws = None
+        ws = torch.empty(need, dtype=torch.uint8, device=device)
+        _gf_workspaces[key] = ws
+    return ws
+
+
+def guided_filter_u8(guide, src, radius, eps, iterations=1, out=None, workspace=None):
+    """Batched cv2.ximgproc.guidedFilter(guide, src, radius, eps), applied `iterations` times
+    with the uint8 result fed back as src (the reference's chained CLI runs)."""
+    torch = _ffi.require_gpu()
+    lib = _ffi.load_library()
+    _chk_images(guide, "guide", torch)
+    _chk_images(src, "src", torch)
+    if guide.shape[:3] != src.shape[:3]:
+        raise ValueError("guide and src must have the same N,H,W")
+    if out is None:
+        out = torch.empty_like(src)
+    n, h, w, scn = src.shape
+    if workspace is None:
+        workspace = gf_workspace(n, h, w, scn, int(radius), src.device, torch)
+    rc = lib.rf_gf_u8(guide.data_ptr(), src.data_ptr(), out.data_ptr(), n, h, w, guide.shape[3],
+                      scn, int(radius), float(eps), int(iterations), workspace.data_ptr(),
+                      workspace.numel(), _ffi.current_stream_ptr(torch))
+    _ffi.check(rc, "rf_gf_u8")
+    return out
+
+
+def _cnn_device_consts(torch, device, weights):
+    from . import image_utils as iu
+    from . import weights as wmod
+    if weights is None:
+        key = (str(device), "default")
+        if key not in _cnn_consts:
+            w = torch.from_numpy(wmod.load_weights()).to(device)
+            lut = torch.from_numpy(iu.srgb_byte_lut()).to(device)
+            _cnn_consts[key] = (w, lut)
+        return _cnn_consts[key]
+    w = np.ascontiguousarray(weights, dtype=np.float32).ravel()
+    if w.size != _ffi.CNN_NPARAMS:
+        raise ValueError("weights must hold %d floats" % _ffi.CNN_NPARAMS)
+    return (torch.from_numpy(w).to(device), torch.from_numpy(iu.srgb_byte_lut()).to(device))
+
+
+def cnn_reflectance_u8(bgr, weights=None, want_float=True, want_u8=True):
+    """Batched reflectance prediction: uint8 BGR [N,H,W,3] -> (r float32 [N,H,W], r_u8 [N,H,W]).
+    r_u8 = trunc(r*255) is the content of the reference's `<base>-r.png`."""
+    torch = _ffi.require_gpu()
+    lib = _ffi.load_library()
+    _chk_images(bgr, "bgr", torch)
+    if bgr.shape[3] != 3:
+        raise ValueError("bgr must have 3 channels")
+    n, h, w, _ = bgr.shape
+    wts, lut = _cnn_device_consts(torch, bgr.device, weights)
+    r = torch.empty((n, h, w), dtype=torch.float32, device=bgr.device) if want_float else None
+    r8 = torch.empty((n, h, w), dtype=torch.uint8, device=bgr.device) if want_u8 else None
+    rc = lib.rf_cnn_reflectance_u8(bgr.data_ptr(), r.data_ptr() if want_float else None,
+                                   r8.data_ptr() if want_u8 else None, n, h, w, wts.data_ptr(),
+                                   lut.data_ptr(), _ffi.current_stream_ptr(torch))
+    _ffi.check(rc, "rf_cnn_reflectance_u8")
+    return r, r8

@@ -1,0 +1,61 @@
+"""``cv2.ximgproc``-shaped entry points backed by the HIP kernels.
+
+These two functions have the call signatures of the OpenCV bindings the reference uses
+(/root/reference/filter_reflectance.py:60-70), take and return host ``numpy`` images, and run
+on the MI355X through librf_hip.so.  A maintainer of the reference can switch to this
+framework by replacing ``cv2.ximgproc`` with this module.
+"""
+import numpy as np
+
+from . import _ffi, ops
+
+
+def _to_device(img, name, torch):
+    arr = np.asarray(img)
+    if arr.dtype != np.uint8:
+        raise ValueError("%s: only 8-bit images are supported (got %s)" % (name, arr.dtype))
+    if arr.ndim == 2:
+        arr = arr[:, :, None]
+    if arr.ndim != 3 or arr.shape[2] not in (1, 3):
+        raise ValueError("%s: expected HxW or HxWx{1,3} (got shape %s)" % (name, arr.shape))
+    return torch.from_numpy(np.ascontiguousarray(arr)).cuda().unsqueeze(0)
+
+
+def _to_host(t, like):
+    out = t[0].cpu().numpy()
+    return out[:, :, 0] if np.ndim(like) == 2 else out
+
+
+def jointBilateralFilter(joint, src, d, sigmaColor, sigmaSpace, dst=None,
+                         borderType=_ffi.BORDER_DEFAULT):
+    """cv2.ximgproc.jointBilateralFilter(joint, src, d, sigmaColor, sigmaSpace[, dst[, borderType]])
+    for uint8 images with 1 or 3 channels each."""
+    torch = _ffi.require_gpu()
+    if np.asarray(joint).shape[:2] != np.asarray(src).shape[:2]:
+        raise ValueError("joint and src must have the same size")
+    j = _to_device(joint, "joint", torch)
+    s = _to_device(src, "src", torch)
+    out = ops.joint_bilateral_u8(j, s, d, sigmaColor, sigmaSpace, border=borderType)
+    res = _to_host(out, src)
+    if dst is not None:
+        np.copyto(dst, res)
+        return dst
+    return res
+
+
+def guidedFilter(guide, src, radius, eps, dst=None, dDepth=-1):
+    """cv2.ximgproc.guidedFilter(guide, src, radius, eps[, dst[, dDepth]]) for a 3-channel
+    uint8 guide and a 1- or 3-channel uint8 src (dDepth must stay -1: uint8 result)."""
+    if dDepth != -1:
+        raise ValueError("guidedFilter: only dDepth=-1 (uint8 result) is supported")
+    torch = _ffi.require_gpu()
+    if np.asarray(guide).shape[:2] != np.asarray(src).shape[:2]:
+        raise ValueError("guide and src must have the same size")
+    g = _to_device(guide, "guide", torch)
+    s = _to_device(src, "src", torch)
+    out = ops.guided_filter_u8(g, s, radius, eps)
+    res = _to_host(out, src)
+    if dst is not None:
+        np.copyto(dst, res)
+        return dst
+    return res

@@ -1,0 +1,84 @@
+"""CPU suite, part 3: the C-ABI library builds for gfx950, loads, exports every symbol the
+header declares, and rejects bad arguments before touching the GPU.  No compute calls."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+import reflectance_filtering_amd as rf
+from reflectance_filtering_amd import _ffi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    with open(os.path.join(ROOT, "include", "reflectance_filtering.h")) as fh:
+        text = re.sub(r"/\*.*?\*/", "", fh.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(rf_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(built):
+    lib = _ffi.load_library()
+    names = _header_functions()
+    assert set(names) == set(_ffi.EXPORTS)
+    for name in names:
+        assert getattr(lib, name) is not None
+    assert lib.rf_version() == 100
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _ffi.LIB_PATH]).decode()
+    for name in names:
+        assert re.search(r"\bT %s\b" % name, out), name
+
+
+def test_code_object_is_gfx950_only(built):
+    tool = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(tool):
+        pytest.skip("llvm-objdump not available")
+    out = subprocess.check_output([tool, "--offloading", _ffi.LIB_PATH],
+                                  stderr=subprocess.STDOUT).decode()
+    archs = set(re.findall(r"gfx[0-9a-f]+", out))
+    assert archs == {"gfx950"}, archs
+
+
+def test_argument_validation_needs_no_gpu(built):
+    lib = _ffi.load_library()
+    bufs = [ctypes.create_string_buffer(64) for _ in range(3)]
+    p, q, o = (ctypes.cast(b, ctypes.c_void_p) for b in bufs)
+    assert lib.rf_jbf_u8(None, q, o, 1, 4, 4, 3, 3, -1, 20.0, 22.0, 4, 0, None) == _ffi.RF_E_BADARG
+    assert b"NULL" in lib.rf_last_error()
+    assert lib.rf_jbf_u8(p, q, o, 1, 4, 4, 2, 3, -1, 20.0, 22.0, 4, 0, None) == _ffi.RF_E_UNSUPPORTED
+    assert lib.rf_jbf_u8(p, q, o, 1, 0, 4, 3, 3, -1, 20.0, 22.0, 4, 0, None) == _ffi.RF_E_BADARG
+    assert lib.rf_jbf_u8(p, q, o, 1, 4, 4, 3, 3, -1, 20.0, 22.0, 9, 0, None) == _ffi.RF_E_UNSUPPORTED
+    assert lib.rf_gf_u8(p, q, o, 1, 4, 4, 1, 3, 2, 1.0, 1, p, 1 << 20, None) == _ffi.RF_E_UNSUPPORTED
+    assert lib.rf_gf_u8(p, q, o, 1, 4, 4, 3, 3, 2, 1.0, 0, p, 1 << 20, None) == _ffi.RF_E_BADARG
+    assert lib.rf_gf_u8(p, q, o, 1, 4, 4, 3, 3, 500, 1.0, 1, p, 1 << 20, None) == _ffi.RF_E_UNSUPPORTED
+    assert lib.rf_gf_u8(p, q, o, 1, 64, 64, 3, 3, 2, 1.0, 1, p, 16, None) == _ffi.RF_E_WORKSPACE
+    assert lib.rf_cnn_reflectance_u8(p, None, None, 1, 4, 4, p, p, None) == _ffi.RF_E_BADARG
+    assert lib.rf_gf_workspace_bytes(1, 100, 200, 3, 3, 45) == 100 * 200 * 12 * 12
+    assert lib.rf_gf_workspace_bytes(1, 100, 200, 3, 2, 45) == 0
+    with pytest.raises(ValueError):
+        _ffi.check(_ffi.RF_E_BADARG, "x")
+    with pytest.raises(_ffi.RFError):
+        _ffi.check(_ffi.RF_E_HIP, "x")
+
+
+def test_operators_fail_loudly_without_gpu(built):
+    import numpy as np
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    img = np.zeros((8, 8, 3), np.uint8)
+    with pytest.raises(_ffi.RFError):
+        rf.apply_filter("bilateral", img, img, 20, 22)
+    with pytest.raises(_ffi.RFError):
+        rf.apply_filter("guided", img, img, 3, 5)
+    with pytest.raises(_ffi.RFError):
+        rf.get_reflectance_caffe(rf.decompose_with_trained_CNN.ReflectanceNet(), img)
+
+
+def test_missing_library_is_an_error(monkeypatch, tmp_path):
+    monkeypatch.setattr(_ffi, "_lib", None)
+    monkeypatch.setattr(_ffi, "LIB_PATH", str(tmp_path / "librf_hip.so"))
+    with pytest.raises(_ffi.RFError):
+        _ffi.load_library()

@@ -1,0 +1,229 @@
+"""CPU suite, part 2: the host-side mirror of the reference's Python API against golden
+vectors captured from the reference itself (tests/golden/make_golden.py)."""
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+
+import reflectance_filtering_amd as rf
+from reflectance_filtering_amd import decompose_with_trained_CNN as dc
+from reflectance_filtering_amd import filter_reflectance as fr
+from reflectance_filtering_amd import image_utils as iu
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_colour_curves_bitwise():
+    g = np.load(os.path.join(G, "colour_tables.npz"))
+    assert np.array_equal(iu.srgb_to_rgb(g["levels"]), g["srgb_to_rgb_levels"])
+    assert np.array_equal(iu.rgb_to_srgb(g["levels"]), g["rgb_to_srgb_levels"])
+    assert np.array_equal(iu.srgb_to_rgb(g["extra"]), g["srgb_to_rgb_extra"])
+    assert np.array_equal(iu.rgb_to_srgb(g["extra"]), g["rgb_to_srgb_extra"])
+    f32 = iu.srgb_to_rgb(g["levels"].astype(np.float32))
+    assert f32.dtype == np.float32 and np.array_equal(f32, g["srgb_to_rgb_levels_f32"])
+    assert abs(float(iu.rgb_to_srgb(np.array([1.0]))[0]) - 0.9676) < 1e-4  # the kept quirk
+    assert np.array_equal(iu.srgb_byte_lut(), g["srgb_to_rgb_levels"].astype(np.float32))
+
+
+def test_normalize_colorize_bitwise():
+    g = np.load(os.path.join(G, "normalize_colorize.npz"))
+    assert np.array_equal(iu.normalize(g["img_small"]), g["normalize_small"])
+    assert np.array_equal(iu.normalize(g["img_big"]), g["normalize_big"])
+    n32 = iu.normalize(g["img_big_f32"])
+    assert n32.dtype == np.float32 and np.array_equal(n32, g["normalize_big_f32"])
+    keep = g["img_big"].copy()
+    iu.normalize(keep)
+    assert np.array_equal(keep, g["img_big"]), "normalize must not modify its argument"
+    refl, shad = iu.colorize(g["inten16"], g["bgr16"])
+    assert np.array_equal(refl, g["colorize_reflectance"])
+    assert np.array_equal(shad, g["colorize_shading"])
+
+
+def test_imwrite_conversion_and_roundtrip(tmp_path):
+    g = np.load(os.path.join(G, "normalize_colorize.npz"))
+    cases = (("small_lin", g["img_small"], False), ("small_srgb", g["img_small"], True),
+             ("big_lin", g["img_big"], False), ("big_srgb", g["img_big"], True),
+             ("big32_lin", g["img_big_f32"], False),
+             ("refl_srgb", g["colorize_reflectance"], True),
+             ("shad_srgb", g["colorize_shading"], True), ("u8_passthrough", g["bgr16"], False),
+             ("inten_lin", g["inten16"], False))
+    for tag, arr, srgb in cases:
+        path = str(tmp_path / (tag + ".png"))
+        iu.imwrite(path, arr, sRGB=srgb)
+        want = g["imwrite_" + tag]
+        back = iu.imread(path)                      # always uint8 HxWx3 BGR, gray replicated
+        assert back.dtype == np.uint8 and back.shape == want.shape[:2] + (3,)
+        want3 = want if want.ndim == 3 else np.repeat(want[:, :, None], 3, axis=2)
+        assert np.array_equal(back, want3), tag
+
+
+def test_imread_imwrite_errors(tmp_path):
+    with pytest.raises(Exception) as e:
+        iu.imread(str(tmp_path / "missing.png"))
+    assert str(e.value) == "Input image not readable: {}".format(tmp_path / "missing.png")
+    bad = str(tmp_path / "no_such_dir" / "x.png")
+    with pytest.raises(Exception) as e:
+        iu.imwrite(bad, np.zeros((2, 2), np.uint8))
+    assert str(e.value) == "Not able to write {}, does the folder exist?".format(bad)
+
+
+def test_builtin_png_codec_roundtrip(tmp_path):
+    rng = np.random.default_rng(0)
+    bgr = rng.integers(0, 256, (13, 17, 3), dtype=np.uint8)
+    gray = rng.integers(0, 256, (13, 17), dtype=np.uint8)
+    assert np.array_equal(iu._png_decode(iu._png_encode(bgr)), bgr)
+    assert np.array_equal(iu._png_decode(iu._png_encode(gray)), np.repeat(gray[:, :, None], 3, 2))
+    if iu._PILImage is not None:  # Pillow's adaptive filters through the built-in decoder
+        p = str(tmp_path / "pil.png")
+        iu._PILImage.fromarray(bgr[:, :, ::-1].copy()).save(p)
+        with open(p, "rb") as fh:
+            assert np.array_equal(iu._png_decode(fh.read()), bgr)
+
+
+def test_caffe_blob_helpers():
+    g = np.load(os.path.join(G, "caffe_blob.npz"))
+    blob = dc.imgCV2_to_caffeBlob(g["bgr8"])
+    assert blob.dtype == np.float64 and np.array_equal(blob, g["blob8"])
+    assert np.array_equal(dc.imgCV2_to_caffeBlob(g["ramp"]), g["blob_ramp"])
+    ok = dc.caffeBlob_to_imgGrayLinear(np.arange(12, dtype=np.float32).reshape(1, 1, 3, 4))
+    assert np.array_equal(ok, g["gray_ok"])
+    for shp, msg in zip(((2, 1, 3, 4), (1, 3, 3, 4)), g["shape_errors"]):
+        with pytest.raises(ValueError) as e:
+            dc.caffeBlob_to_imgGrayLinear(np.zeros(shp, np.float32))
+        assert str(e.value) == str(msg)
+
+
+def test_caffemodel_decoder_and_shipped_weights():
+    g = np.load(os.path.join(G, "cnn_forward.npz"))
+    shipped = rf.weights.load_weights()
+    assert shipped.dtype == np.float32 and np.array_equal(shipped, g["weights"])
+    ref_model = "/root/reference/learned_weights.caffemodel"
+    if os.path.exists(ref_model):  # only in the build container
+        assert np.array_equal(rf.weights.load_weights(ref_model), shipped)
+        layers = rf.weights.read_caffemodel(ref_model)
+        assert set(rf.weights.CONV_LAYERS) <= set(layers)
+
+
+def test_reflectance_net_blob_to_bytes_roundtrip():
+    g = np.load(os.path.join(G, "cnn_forward.npz"))
+    net = dc.ReflectanceNet()
+    net.blobs["images"].reshape(1, 3, 32, 32)
+    net.blobs["images"].data[...] = dc.imgCV2_to_caffeBlob(g["bgr32"])
+    assert np.array_equal(net.blobs["images"].data, g["blob32"])
+    assert np.array_equal(net._blob_to_bytes()[0], g["bgr32"])
+    net.blobs["images"].data[0, 0, 0, 0] = 0.123456  # not an sRGB byte level
+    with pytest.raises(ValueError):
+        net._blob_to_bytes()
+
+
+class _Recorder(object):
+    def __init__(self):
+        self.calls = []
+
+    def jointBilateralFilter(self, *a, **k):
+        self.calls.append(("jbf", a, k))
+        return np.full_like(a[1], 7)
+
+    def guidedFilter(self, *a, **k):
+        self.calls.append(("gf", a, k))
+        return np.full_like(k["src"], 9)
+
+
+def test_apply_filter_plumbing_matches_reference(monkeypatch):
+    with open(os.path.join(G, "cli_plumbing.json")) as fh:
+        gold = json.load(fh)
+    rec = _Recorder()
+    monkeypatch.setattr(fr, "ximgproc", rec)
+    a = np.full((4, 5, 3), 0x11, np.uint8)
+    b = np.full((4, 5, 3), 0x22, np.uint8)
+    out = fr.apply_filter("bilateral", a, b, 20, 22)
+    kind, args, kwargs = rec.calls[-1]
+    gcall = gold["apply_filter_bilateral"]["calls"][0]
+    assert kind == "jbf" and args[0] is b and args[1] is a      # (joint, image) positional
+    assert kwargs == gcall[2] == {"d": -1, "sigmaColor": 20, "sigmaSpace": 22}
+    assert int(out[0, 0, 0]) == gold["apply_filter_bilateral"]["result_fill"]
+    out = fr.apply_filter("guided", a, b, 3.0, 45.9)
+    kind, args, kwargs = rec.calls[-1]
+    gcall = gold["apply_filter_guided"]["calls"][0]
+    assert kind == "gf" and args == () and kwargs["guide"] is b and kwargs["src"] is a
+    assert kwargs["radius"] == gcall[2]["radius"] == 45 and kwargs["eps"] == gcall[2]["eps"] == 3.0
+    for key, args in (("sigma_color_zero", ("bilateral", a, b, 0, 22)),
+                      ("sigma_spatial_negative", ("guided", a, b, 3, -1)),
+                      ("bad_type", ("median", a, b, 3, 3))):
+        with pytest.raises(ValueError) as e:
+            fr.apply_filter(*args)
+        assert [type(e.value).__name__, str(e.value)] == gold["apply_filter_errors"][key]
+
+
+def test_read_filter_write_names_and_errors(monkeypatch, tmp_path):
+    with open(os.path.join(G, "cli_plumbing.json")) as fh:
+        gold = json.load(fh)
+    monkeypatch.setattr(fr, "ximgproc", _Recorder())
+    img = np.full((4, 5, 3), 0x11, np.uint8)
+    src = str(tmp_path / "photo.final.png")
+    gui = str(tmp_path / "guide.png")
+    iu.imwrite(src, img)
+    iu.imwrite(gui, img)
+    out_dir = tmp_path / "dir"
+    out_dir.mkdir()
+    for tag, (ftype, sc, ss) in {"int_like": ("bilateral", 20.0, 22.0),
+                                 "fractional": ("guided", 3.5, 45.25),
+                                 "python_int": ("guided", 7, 52)}.items():
+        res = fr.read_filter_write(ftype, src, gui, sc, ss, str(out_dir))
+        want = os.path.basename(gold["read_filter_write"][tag]["written"][0])
+        assert os.path.exists(str(out_dir / want)), want
+        assert np.array_equal(iu.imread(str(out_dir / want)), res)
+    with pytest.raises(Exception) as e:
+        fr.read_filter_write("guided", str(tmp_path / "missing.png"), gui, 3.0, 45.0, str(out_dir))
+    assert str(e.value).startswith("Input image not readable: ")
+    with pytest.raises(Exception) as e:
+        fr.read_filter_write("guided", src, gui, 3.0, 45.0, str(tmp_path / "nonexistent"))
+    assert "does the folder exist?" in str(e.value)
+    assert "photo.final_guided_c3.0s45.0.png" in str(e.value)
+
+
+def test_cli_without_arguments_prints_help_and_hints(capsys):
+    assert fr.main([]) == 0
+    out = capsys.readouterr().out
+    assert "--filter_type=bilateral --sigma_color=20 --sigma_spatial=22" in out
+    assert "--filter_type=guided --sigma_color=7 --sigma_spatial=52" in out
+    assert "--filter_type=guided --sigma_color=3 --sigma_spatial=45" in out
+    for flag in ("--filename_in", "--guidance_in", "--path_out", "--sigma_color",
+                 "--sigma_spatial", "--filter_type"):
+        assert flag in out
+    assert dc.main([]) == 0
+    assert "--filename_in" in capsys.readouterr().out
+
+
+def test_decompose_image_outputs_match_reference(monkeypatch, tmp_path):
+    """decompose_image with the network output injected: file names and all three PNGs must
+    equal what the reference wrote (captured with the same injected output)."""
+    d = np.load(os.path.join(G, "decompose_outputs.npz"))
+    src = str(tmp_path / "scene.01.png")
+    iu.imwrite(src, d["scene"])
+
+    class FakeNet(dc.ReflectanceNet):
+        def forward(self):
+            self.blobs["reflectance_intensity"].data = d["r"][np.newaxis, np.newaxis]
+
+    monkeypatch.setattr(dc, "ReflectanceNet", FakeNet)
+    r = dc.decompose_image(src, str(tmp_path))
+    assert np.array_equal(r, d["r"])
+    for name, key in (("scene.01-r.png", "r_png"), ("scene.01-r_colorized.png", "r_colorized_png"),
+                      ("scene.01-s_colorized.png", "s_colorized_png")):
+        got = iu.imread(str(tmp_path / name))
+        want = d[key] if d[key].ndim == 3 else np.repeat(d[key][:, :, None], 3, axis=2)
+        assert np.array_equal(got, want), name
+
+
+def test_no_oracle_in_product():
+    """The product package must never import or load the oracle (no CPU fallback)."""
+    pkg = os.path.dirname(rf.__file__)
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                with open(os.path.join(root, f)) as fh:
+                    text = fh.read()
+                assert "oracle" not in text.replace("no oracle", ""), os.path.join(root, f)

@@ -1,0 +1,179 @@
+"""CPU suite, part 1: the oracle itself.
+
+The C restatement (T1, oracle/rf_oracle.c) is checked against (a) the golden vectors captured
+from the reference's own Python helpers, (b) the float64 definitions (T0) and (c) known-answer
+cases.  Nothing here touches the GPU or the product library.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle as co
+from oracle import t0_numpy as t0
+from tests import synth
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+# ------------------------------------------------------------------ shared primitives
+def test_border_interpolate_matches_numpy_pad():
+    for length in (1, 2, 3, 7, 40):
+        base = np.arange(length)
+        for pad in (1, 5, 3 * length + 2):
+            for border, mode in ((co.BORDER_REFLECT_101, "reflect"), (co.BORDER_REFLECT, "symmetric"),
+                                 (co.BORDER_REPLICATE, "edge"), (co.BORDER_WRAP, "wrap")):
+                want = np.pad(base, pad, mode=mode)
+                got = [co.border_interpolate(p, length, border) for p in range(-pad, length + pad)]
+                assert list(want) == got, (length, pad, mode)
+    assert co.border_interpolate(-1, 5, co.BORDER_CONSTANT) == -1
+
+
+def test_jbf_radius_and_tap_table():
+    # d=-1, sigma_space=22 -> cvRound(33.0)=33, 3409 taps; 28 -> 42, 5525 taps
+    assert co.jbf_radius(-1, 22.0) == 33
+    assert co.jbf_radius(-1, 28.0) == 42
+    assert co.jbf_radius(-1, 1.0) == 2      # cvRound(1.5) = 2 (half to even)
+    assert co.jbf_radius(-1, 0.3) == 1      # max(radius, 1)
+    assert co.jbf_radius(9, 22.0) == 4
+    di, dj, sw = co.jbf_taps(33, 22.0)
+    assert len(di) == 3409
+    assert (di[0], dj[0]) == (-33, 0) and (di[-1], dj[-1]) == (33, 0)
+    order = di.astype(np.int64) * 1000 + dj
+    assert np.all(np.diff(order) > 0), "taps must be row-major"
+    k0 = np.flatnonzero((di == 0) & (dj == 0))[0]
+    assert sw[k0] == 1.0
+    assert len(co.jbf_taps(42, 28.0)[0]) == 5525
+
+
+def test_jbf_color_lut_underflows_to_zero():
+    lut = co.jbf_color_lut(20.0, 3)
+    assert lut.shape == (768,) and lut[0] == 1.0
+    first_zero = int(np.flatnonzero(lut == 0)[0])
+    assert 280 <= first_zero <= 300  # exp(-a^2/800) leaves float32 near a = 288
+    assert np.all(np.diff(lut) <= 0)
+
+
+# ------------------------------------------------------------------ joint bilateral
+@pytest.mark.parametrize("jcn,scn", [(3, 3), (1, 3), (3, 1), (1, 1)])
+def test_jbf_t1_matches_float64_definition(jcn, scn):
+    joint = synth.scene_u8(40, 56, seed=11)
+    src = synth.scene_u8(40, 56, seed=12)
+    joint = joint if jcn == 3 else joint[:, :, 0]
+    src = src if scn == 3 else src[:, :, 1]
+    got = co.joint_bilateral_filter(joint, src, -1, 20, 22)
+    want, ntaps = t0.joint_bilateral_f64(joint, src, 20, 22)
+    assert ntaps == 3409
+    assert got.shape == src.shape and got.dtype == np.uint8
+    # float32 sequential accumulation vs float64: < 1e-3 before rounding, so the bytes agree
+    # except where the exact value sits within 1e-3 of a .5 boundary
+    diff = np.abs(got.astype(np.float64) - want)
+    assert diff.max() <= 0.5 + 1e-3
+    assert np.mean(got != np.clip(np.rint(want), 0, 255)) < 5e-3
+
+
+def test_jbf_known_answers():
+    rng = np.random.default_rng(3)
+    const = np.full((20, 30, 3), 77, np.uint8)
+    src = rng.integers(0, 256, (20, 30, 3), dtype=np.uint8)
+    # constant src -> identity whatever the joint is
+    assert np.array_equal(co.joint_bilateral_filter(src, const, -1, 20, 5), const)
+    # constant joint -> colour weight 1 everywhere -> disk-masked Gaussian blur of src
+    got = co.joint_bilateral_filter(const, src, -1, 20, 3)
+    want, _ = t0.joint_bilateral_f64(const, src, 1e9, 3)
+    assert np.abs(got - want).max() <= 0.5 + 1e-3
+    # tiny sigma_color with a noisy joint -> only the centre tap survives -> identity
+    joint = (np.arange(20 * 30 * 3).reshape(20, 30, 3) * 37 % 251).astype(np.uint8)
+    assert np.array_equal(co.joint_bilateral_filter(joint, src, -1, 0.05, 2), src)
+
+
+def test_jbf_image_smaller_than_radius_and_flags():
+    joint = synth.scene_u8(9, 7, seed=5)
+    src = synth.scene_u8(9, 7, seed=6)
+    got = co.joint_bilateral_filter(joint, src, -1, 25, 22)  # radius 33 > image: multi-bounce
+    want, _ = t0.joint_bilateral_f64(joint, src, 25, 22)
+    assert np.abs(got - want).max() <= 0.5 + 1e-3
+    a = co.joint_bilateral_filter(joint, src, -1, 25, 4)
+    b = co.joint_bilateral_filter(joint, src, -1, 25, 4, flags=co.FLAG_TRUE_DIVISION)
+    assert np.abs(a.astype(int) - b.astype(int)).max() <= 1
+    with pytest.raises(ValueError):
+        co.joint_bilateral_filter(joint[:, :, :2], src, -1, 25, 4)
+
+
+# ------------------------------------------------------------------ guided filter
+def test_box_mean_matches_float64_and_is_exact_on_integers():
+    rng = np.random.default_rng(4)
+    ints = rng.integers(0, 65026, (37, 53)).astype(np.float32)
+    for r in (1, 4, 20, 45):  # 45 > both image dimensions: multi-bounce BORDER_REFLECT
+        got = co.box_mean_f32(ints, r)
+        want = t0.box_mean_f64(ints, r)
+        # integer inputs: sums are exact, the only roundings are *scale and ->float32
+        k2 = (2 * r + 1) ** 2
+        exact = np.rint(want * k2)
+        assert np.array_equal(got, (exact * (1.0 / k2)).astype(np.float32))
+    fl = rng.standard_normal((37, 53)).astype(np.float32)
+    assert np.abs(co.box_mean_f32(fl, 6) - t0.box_mean_f64(fl, 6)).max() < 1e-6
+
+
+@pytest.mark.parametrize("scn", [3, 1])
+def test_gf_t1_close_to_float64_definition(scn):
+    guide = synth.flat_guide_u8(64, 80, seed=21, cells=12)
+    src = synth.reflectance_like_u8(64, 80, seed=22)
+    src = src if scn == 3 else src[:, :, 0]
+    got, qf = co.guided_filter(guide, src, 9, 3.0, return_float=True)
+    want = t0.guided_filter_f64(guide, src, 9, 3.0)
+    assert got.shape == src.shape
+    # cancellation in cov = E[Ip]-E[I]E[p] at float32 limits the agreement
+    assert np.abs(qf - want).max() < 0.5
+    assert np.mean(np.abs(qf - want)) < 0.05
+    assert np.array_equal(got, np.clip(np.rint(qf), 0, 255).astype(np.uint8))
+
+
+def test_gf_known_answers():
+    guide = synth.scene_u8(48, 48, seed=31)
+    const = np.full((48, 48, 3), 140, np.uint8)
+    # constant src: cov(I,p)=0 -> alpha=0, beta=mean(p)=p
+    assert np.array_equal(co.guided_filter(guide, const, 7, 3.0), const)
+    # huge eps: alpha -> 0, output = box(box(p))
+    src = synth.scene_u8(48, 48, seed=32)
+    got, qf = co.guided_filter(guide, src, 3, 1e12, return_float=True)
+    bb = np.stack([t0.box_mean_f64(t0.box_mean_f64(src[:, :, c], 3), 3) for c in range(3)], 2)
+    assert np.abs(qf - bb).max() < 1e-2
+    with pytest.raises(ValueError):
+        co.guided_filter(guide[:, :, 0], src, 3, 1.0)  # 1-channel guide not restated
+
+
+# ------------------------------------------------------------------ CNN + colour pipeline
+def test_srgb_lut_equals_reference_table():
+    g = np.load(os.path.join(G, "colour_tables.npz"))
+    assert np.array_equal(co.srgb_lut(), g["srgb_to_rgb_levels"].astype(np.float32))
+    c = np.load(os.path.join(G, "caffe_blob.npz"))
+    assert np.array_equal(co.srgb_lut(), c["blob_ramp_f32"][0, 0, 0])
+
+
+def test_cnn_oracle_against_reference_plumbing_and_float64():
+    g = np.load(os.path.join(G, "cnn_forward.npz"))
+    w = g["weights"]
+    assert w.shape == (4513,) and abs(float(w[-1]) - 0.24792) < 1e-4
+    r, r8 = co.cnn_reflectance(g["bgr32"], w)
+    # r32 = reference get_reflectance_caffe() around a float64 forward of the same weights
+    assert np.abs(r - g["r32"]).max() < 2e-6
+    r64 = t0.cnn_reflectance_f64(g["bgr32"], w)
+    assert np.abs(r - r64).max() < 2e-6
+    assert np.array_equal(r8, (r * 255).astype(np.uint8))
+    ramp_r, _ = co.cnn_reflectance(g["ramp"], w)
+    assert np.abs(ramp_r - g["r_ramp"]).max() < 2e-6
+    probes = {0: 0.4797, 32: 0.5760, 64: 0.6776, 96: 0.7511, 128: 0.8179, 160: 0.8685,
+              192: 0.9106, 224: 0.9459}  # SURVEY App. B grey-ramp response
+    for v, want in probes.items():
+        assert abs(float(ramp_r[0, v]) - want) < 1e-4
+
+
+def test_r_png_bytes_match_reference_imwrite():
+    d = np.load(os.path.join(G, "decompose_outputs.npz"))
+    g = np.load(os.path.join(G, "cnn_forward.npz"))
+    r, r8 = co.cnn_reflectance(d["scene"], g["weights"])
+    assert np.abs(r - d["r"]).max() < 2e-6
+    # the reference truncates r*255; 1-ulp differences in r may move a byte by one, rarely
+    delta = r8.astype(int) - d["r_png"].astype(int)
+    assert np.abs(delta).max() <= 1 and np.mean(delta != 0) < 0.01
