@@ -36,6 +36,10 @@ def load_library():
     with _lock:
         if _lib is not None:
             return _lib
+        # torch bundles its own libamdhip64 / libhsa-runtime64.  The device pointers and the
+        # stream we are handed belong to THAT runtime instance, so it has to be in the process
+        # before librf_hip.so resolves its libamdhip64.so.7 dependency (same SONAME -> shared).
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise RFError("%s not found: build it with `python -c 'import __graft_entry__ as g; "
                           "g.build()'` or `make -C reflectance_filtering_amd/csrc` "

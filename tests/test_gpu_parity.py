@@ -1,0 +1,242 @@
+"""GPU suite: the HIP path (through the C ABI) against the CPU oracle, bit for bit.
+
+Sizes are chosen so the oracle finishes in seconds; full-size behaviour is covered through
+locality (the bilateral filter of a crop with its halo equals the crop of the filtered image),
+batch independence and idempotence-style properties.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def env(built):
+    import torch
+    import reflectance_filtering_amd as rf
+    from oracle import c_oracle as co
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    rf._ffi.load_library()
+    return rf, co, torch
+
+
+def _dev(torch, *imgs):
+    return [torch.from_numpy(np.ascontiguousarray(i if i.ndim == 4 else i[None])).cuda()
+            for i in imgs]
+
+
+# ------------------------------------------------------------------------------ JBF
+@pytest.mark.parametrize("h,w,sc,ss", [(96, 160, 20, 22), (70, 45, 20, 22), (33, 129, 15, 28),
+                                       (64, 64, 7.5, 3.3), (40, 200, 60, 10)])
+def test_jbf_matches_oracle_bitwise(env, h, w, sc, ss):
+    from tests import synth
+    rf, co, torch = env
+    joint = synth.scene_u8(h, w, seed=h + w)
+    src = synth.reflectance_like_u8(h, w, seed=h * w)
+    got = rf.ximgproc.jointBilateralFilter(joint, src, -1, sc, ss)
+    want = co.joint_bilateral_filter(joint, src, -1, sc, ss)
+    assert got.dtype == np.uint8 and got.shape == src.shape
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("jcn,scn", [(1, 3), (3, 1), (1, 1)])
+def test_jbf_channel_combinations(env, jcn, scn):
+    from tests import synth
+    rf, co, torch = env
+    joint = synth.scene_u8(80, 100, seed=1)
+    src = synth.scene_u8(80, 100, seed=2)
+    joint = joint if jcn == 3 else joint[:, :, 2]
+    src = src if scn == 3 else src[:, :, 0]
+    got = rf.ximgproc.jointBilateralFilter(joint, src, -1, 20, 22)
+    assert np.array_equal(got, co.joint_bilateral_filter(joint, src, -1, 20, 22))
+
+
+def test_jbf_rgb_guidance_and_explicit_diameter(env):
+    from tests import synth
+    rf, co, torch = env
+    joint = synth.scene_u8(120, 90, seed=3)
+    src = synth.scene_u8(120, 90, seed=4)
+    for d in (-1, 9, 31):
+        got = rf.ximgproc.jointBilateralFilter(joint, src, d, 25, 6)
+        assert np.array_equal(got, co.joint_bilateral_filter(joint, src, d, 25, 6)), d
+
+
+def test_jbf_image_smaller_than_radius(env):
+    from tests import synth
+    rf, co, torch = env
+    for h, w in ((9, 7), (1, 50), (50, 1), (2, 2)):
+        joint = synth.scene_u8(h, w, seed=5)
+        src = synth.scene_u8(h, w, seed=6)
+        got = rf.ximgproc.jointBilateralFilter(joint, src, -1, 25, 22)
+        assert np.array_equal(got, co.joint_bilateral_filter(joint, src, -1, 25, 22)), (h, w)
+
+
+def test_jbf_border_types_flags_and_generic_kernel(env):
+    from tests import synth
+    rf, co, torch = env
+    ffi = rf._ffi
+    joint = synth.scene_u8(50, 70, seed=7)
+    src = synth.scene_u8(50, 70, seed=8)
+    j, s = _dev(torch, joint, src)
+    for border in (ffi.BORDER_CONSTANT, ffi.BORDER_REPLICATE, ffi.BORDER_REFLECT, ffi.BORDER_WRAP,
+                   ffi.BORDER_REFLECT_101):
+        want = co.joint_bilateral_filter(joint, src, -1, 20, 8, border=border)
+        for flags in (0, ffi.JBF_FORCE_GENERIC):
+            got = rf.ops.joint_bilateral_u8(j, s, -1, 20, 8, border=border, flags=flags)
+            assert np.array_equal(got[0].cpu().numpy(), want), (border, flags)
+    want = co.joint_bilateral_filter(joint, src, -1, 20, 8, flags=co.FLAG_TRUE_DIVISION)
+    got = rf.ops.joint_bilateral_u8(j, s, -1, 20, 8, flags=ffi.JBF_TRUE_DIVISION)
+    assert np.array_equal(got[0].cpu().numpy(), want)
+    # very wide colour kernel: the LUT has no zero tail (exercises the untruncated table)
+    want = co.joint_bilateral_filter(joint, src, -1, 400, 5)
+    assert np.array_equal(rf.ops.joint_bilateral_u8(j, s, -1, 400, 5)[0].cpu().numpy(), want)
+    # radius too large for the LDS tile -> generic kernel is picked automatically
+    want = co.joint_bilateral_filter(joint, src, -1, 20, 40)
+    assert np.array_equal(rf.ops.joint_bilateral_u8(j, s, -1, 20, 40)[0].cpu().numpy(), want)
+
+
+def test_jbf_known_answers_on_device(env):
+    rf, co, torch = env
+    rng = np.random.default_rng(0)
+    const = np.full((70, 130, 3), 99, np.uint8)
+    noise = rng.integers(0, 256, (70, 130, 3), dtype=np.uint8)
+    assert np.array_equal(rf.ximgproc.jointBilateralFilter(noise, const, -1, 20, 22), const)
+    assert np.array_equal(rf.ximgproc.jointBilateralFilter(noise, noise.copy(), -1, 0.05, 22), noise)
+
+
+def test_jbf_full_1080p_locality_and_batch(env):
+    """BASELINE config C2 size: compare crops of the full-size result with the oracle run on
+    the crop plus its halo (the filter is local), and check batch independence."""
+    from tests import synth
+    rf, co, torch = env
+    h, w, r = 1080, 1920, 33
+    joint = synth.scene_u8(h, w, seed=100)
+    src = synth.reflectance_like_u8(h, w, seed=101)
+    j, s = _dev(torch, joint, src)
+    out = rf.ops.joint_bilateral_u8(j, s, -1, 20, 22)[0].cpu().numpy()
+    for (y0, x0, ch, cw) in ((500, 900, 24, 40), (r, w - r - 30, 16, 30), (h - r - 20, r, 20, 25)):
+        jc = joint[y0 - r:y0 + ch + r, x0 - r:x0 + cw + r]
+        sc_ = src[y0 - r:y0 + ch + r, x0 - r:x0 + cw + r]
+        want = co.joint_bilateral_filter(jc, sc_, -1, 20, 22)[r:r + ch, r:r + cw]
+        assert np.array_equal(out[y0:y0 + ch, x0:x0 + cw], want), (y0, x0)
+    # image borders: top-left and bottom-right corners including the reflected halo
+    want = co.joint_bilateral_filter(joint[:60 + r, :50 + r], src[:60 + r, :50 + r], -1, 20, 22)
+    assert np.array_equal(out[:60, :50], want[:60, :50])
+    want = co.joint_bilateral_filter(joint[-(40 + r):, -(40 + r):], src[-(40 + r):, -(40 + r):],
+                                     -1, 20, 22)
+    assert np.array_equal(out[-40:, -40:], want[-40:, -40:])
+    # a batch is filtered image by image
+    j2 = torch.cat([j, torch.flip(j, dims=[1])])
+    s2 = torch.cat([s, torch.flip(s, dims=[1])])
+    o2 = rf.ops.joint_bilateral_u8(j2, s2, -1, 20, 22)
+    assert torch.equal(o2[0], torch.from_numpy(out).cuda())
+    alone = rf.ops.joint_bilateral_u8(j2[1:].contiguous(), s2[1:].contiguous(), -1, 20, 22)
+    assert torch.equal(o2[1], alone[0])
+    # (a flipped input does NOT give the flipped output bit for bit: the tap order is part of
+    #  the contract and it is not flip-symmetric)
+
+
+# ------------------------------------------------------------------------------ GF
+@pytest.mark.parametrize("h,w,r,eps", [(256, 256, 52, 7.0), (256, 256, 45, 3.0), (130, 517, 9, 3.0),
+                                       (64, 700, 20, 0.5), (37, 41, 45, 3.0), (90, 64, 1, 1e-3)])
+def test_gf_matches_oracle_bitwise(env, h, w, r, eps):
+    from tests import synth
+    rf, co, torch = env
+    guide = synth.flat_guide_u8(h, w, seed=r, cells=25) if r != 9 else synth.scene_u8(h, w, seed=9)
+    src = synth.reflectance_like_u8(h, w, seed=h)
+    got = rf.ximgproc.guidedFilter(guide, src, r, eps)
+    want = co.guided_filter(guide, src, r, eps)
+    assert got.dtype == np.uint8 and got.shape == src.shape
+    assert np.array_equal(got, want)
+
+
+def test_gf_single_channel_src_and_iterations(env):
+    from tests import synth
+    rf, co, torch = env
+    guide = synth.flat_guide_u8(150, 210, seed=1)
+    src = synth.reflectance_like_u8(150, 210, seed=2)
+    got = rf.ximgproc.guidedFilter(guide, src[:, :, 0], 12, 3.0)
+    assert got.shape == (150, 210)
+    assert np.array_equal(got, co.guided_filter(guide, src[:, :, 0], 12, 3.0))
+    # 3x GF with a uint8 hand-off between passes == three CLI runs of the reference
+    want = src
+    for _ in range(3):
+        want = co.guided_filter(guide, want, 12, 3.0)
+    g, s = _dev(torch, guide, src)
+    out = rf.apply_filter_batch("guided", s, g, 3.0, 12.7, iterations=3)
+    assert np.array_equal(out[0].cpu().numpy(), want)
+    # in place (dst aliases src) and tiny workspace (one image in flight) give the same bytes
+    batch_g = torch.cat([g, g, g])
+    batch_s = torch.cat([s, torch.flip(s, dims=[2]), s])
+    one = rf._ffi.load_library().rf_gf_workspace_bytes(1, 150, 210, 3, 3, 12)
+    ws = torch.empty(one, dtype=torch.uint8, device="cuda")
+    a = rf.ops.guided_filter_u8(batch_g, batch_s, 12, 3.0, iterations=2)
+    b = batch_s.clone()
+    rf.ops.guided_filter_u8(batch_g, b, 12, 3.0, iterations=2, out=b, workspace=ws)
+    assert torch.equal(a, b) and torch.equal(a[0], a[2])
+
+
+def test_gf_1080p_against_oracle(env):
+    from tests import synth
+    rf, co, torch = env
+    guide = synth.flat_guide_u8(1080, 1920, seed=50, cells=60)
+    src = synth.reflectance_like_u8(1080, 1920, seed=51)
+    got = rf.ximgproc.guidedFilter(guide, src, 45, 3.0)
+    assert np.array_equal(got, co.guided_filter(guide, src, 45, 3.0))
+
+
+# ------------------------------------------------------------------------------ CNN
+def test_cnn_matches_oracle_and_golden(env):
+    from tests import synth
+    rf, co, torch = env
+    g = np.load(os.path.join(G, "cnn_forward.npz"))
+    w = rf.weights.load_weights()
+    imgs = [g["bgr32"], synth.scene_u8(333, 500, seed=77)]
+    for img in imgs:
+        r, r8 = rf.get_reflectance_batch(_dev(torch, img)[0])
+        want_r, want_r8 = co.cnn_reflectance(img, w)
+        r, r8 = r[0].cpu().numpy(), r8[0].cpu().numpy()
+        # contract: within 2e-7 of the oracle (1-2 ulp of float32 in [0.5,1)); observed: equal
+        assert np.abs(r - want_r).max() <= 2e-7
+        d8 = np.abs(r8.astype(int) - want_r8.astype(int))
+        assert d8.max() <= 1 and np.mean(d8 != 0) < 1e-4
+    r, _ = rf.get_reflectance_batch(_dev(torch, g["bgr32"])[0])
+    assert np.abs(r[0].cpu().numpy() - g["r32"]).max() < 2e-6  # reference plumbing + f64 forward
+    net = rf.decompose_with_trained_CNN.ReflectanceNet()
+    out = rf.get_reflectance_caffe(net, g["bgr32"])
+    assert out.shape == (32, 32) and out.dtype == np.float32
+    assert np.array_equal(out, r[0].cpu().numpy())
+
+
+# ------------------------------------------------------------------------------ CLI chain
+def test_cli_chain_bf_cnn_cnn(env, tmp_path):
+    """BASELINE config C3 in miniature: decompose CLI -> `-r.png` -> filter CLI with the
+    prediction as its own guidance, compared with the oracle run on the same files."""
+    from tests import synth
+    rf, co, torch = env
+    iu = rf.image_utils
+    scene = synth.scene_u8(111, 167, seed=123)
+    src = str(tmp_path / "img.png")
+    iu.imwrite(src, scene)
+    assert rf.decompose_with_trained_CNN.main(["--filename_in=" + src,
+                                               "--path_out=" + str(tmp_path)]) == 0
+    r_png = iu.imread(str(tmp_path / "img-r.png"))
+    _, want_r8 = co.cnn_reflectance(scene, rf.weights.load_weights())
+    assert np.array_equal(r_png[:, :, 0], want_r8) and np.array_equal(r_png[:, :, 0], r_png[:, :, 2])
+    for name in ("img-r_colorized.png", "img-s_colorized.png"):
+        assert os.path.exists(str(tmp_path / name))
+    rpath = str(tmp_path / "img-r.png")
+    assert rf.filter_reflectance.main(["--filter_type=bilateral", "--sigma_color=20",
+                                       "--sigma_spatial=22", "--filename_in=" + rpath,
+                                       "--guidance_in=" + rpath, "--path_out=" + str(tmp_path)]) == 0
+    out = iu.imread(str(tmp_path / "img-r_bilateral_c20.0s22.0.png"))
+    assert np.array_equal(out, co.joint_bilateral_filter(r_png, r_png.copy(), -1, 20, 22))
+    assert rf.filter_reflectance.main(["--filter_type=guided", "--sigma_color=3",
+                                       "--sigma_spatial=45", "--filename_in=" + rpath,
+                                       "--guidance_in=" + src, "--path_out=" + str(tmp_path)]) == 0
+    out = iu.imread(str(tmp_path / "img-r_guided_c3.0s45.0.png"))
+    assert np.array_equal(out, co.guided_filter(scene, r_png, 45, 3.0))
