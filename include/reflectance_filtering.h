@@ -43,6 +43,7 @@ extern "C" {
 /* rf_jbf_u8 flags */
 #define RF_JBF_TRUE_DIVISION 1 /* dst = sum / wsum; default is OpenCV's sum * (1.f / wsum) */
 #define RF_JBF_FORCE_GENERIC 2 /* use the untiled global-memory kernel (debug / cross-check) */
+#define RF_JBF_TUNE_SHIFT 8    /* bits 8..11: kernel-variant override used by the benchmarks; 0 = auto */
 
 int rf_version(void);
 const char *rf_last_error(void);

@@ -31,6 +31,10 @@ constexpr int kPix = 4;        // outputs per lane (horizontal)
 constexpr int kThreads = 512;  // 16 lanes across x 32 rows
 constexpr int kLutRep = 32;    // LUT replicas = LDS banks of ds_read_b32
 constexpr int kMaxLds = 160 * 1024;
+constexpr int kTlw2 = 144;     // v2 tile row pitch in texels (covers radius <= 36)
+
+typedef uint32_t uint2v __attribute__((ext_vector_type(2)));
+typedef float float4v __attribute__((ext_vector_type(4)));
 
 struct JbfTables {
     int device = -1;
@@ -46,6 +50,10 @@ struct JbfTables {
     float *d_sw = nullptr;      // [maxk]
     int *d_hw = nullptr;        // [2r+1] half-width of the disk on tap row i
     float *d_swpad = nullptr;   // [2r+1][sw_stride]: zeros | weights j=-hw..hw | zeros
+    // v2: rows |i| = 0..r, each sw_len = 2*(r4+4) floats, centre at index r4+4, zeros outside
+    // the disk (the weights are symmetric in i and in j)
+    int r4 = 0, sw_len = 0;
+    float *d_swsym = nullptr;
 };
 
 std::mutex g_mu;
@@ -59,6 +67,7 @@ void free_tables(JbfTables &t)
     (void)hipFree(t.d_sw);
     (void)hipFree(t.d_hw);
     (void)hipFree(t.d_swpad);
+    (void)hipFree(t.d_swsym);
 }
 
 // Host-side parameter tables, computed in double exactly like jointBilateralFilter_8u does.
@@ -111,6 +120,15 @@ int get_tables(int radius, int joint_cn, double sigma_color, double sigma_space,
             swpad[(size_t)(i + radius) * t.sw_stride + (j + radius + kPix - 1)] = wgt;
         }
     t.maxk = (int)di.size();
+    t.r4 = (radius + 3) & ~3;
+    t.sw_len = 2 * (t.r4 + 4);
+    std::vector<float> swsym((size_t)(radius + 1) * t.sw_len, 0.0f);
+    for (size_t k = 0; k < di.size(); k++)
+        if (di[k] >= 0)
+            swsym[(size_t)di[k] * t.sw_len + (t.r4 + 4) + dj[k]] = sw[k];
+    RF_HIP_CHECK(hipMalloc(&t.d_swsym, sizeof(float) * swsym.size()));
+    RF_HIP_CHECK(hipMemcpy(t.d_swsym, swsym.data(), sizeof(float) * swsym.size(),
+                           hipMemcpyHostToDevice));
     RF_HIP_CHECK(hipMalloc(&t.d_lut, sizeof(float) * nlut));
     RF_HIP_CHECK(hipMalloc(&t.d_di, sizeof(int) * t.maxk));
     RF_HIP_CHECK(hipMalloc(&t.d_dj, sizeof(int) * t.maxk));
@@ -296,6 +314,274 @@ __global__ __launch_bounds__(kThreads) void jbf_tiled_kernel(
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Tiled kernel, software-pipelined (v2).
+//
+// Same tile idea as above, plus:
+//   * the tap row is walked in groups of 4 columns starting at a multiple of 4, so the texel
+//     address of column (group g, u) is  lane_base + u*(TLW/4) + g : one VALU add per group,
+//     immediates for the rest, and the spatial weights of the 4 columns x 4 outputs are a
+//     7-float window of the (symmetric) weight row, fetched from LDS as two aligned float4
+//     broadcasts per group (no scalar-memory loads inside the loop, so LDS waits stay counted);
+//   * a 3-stage pipeline over columns: the texel of column c+2 and the four LUT gathers of
+//     column c+1 are in flight while column c is accumulated;
+//   * TH rows per tile (16*TH threads): 32 -> 2 waves/SIMD, 48 -> 3 waves/SIMD;
+//   * LUTREP replicas of the colour LUT (32 = conflict-free, 16/8 trade conflicts for LDS).
+// Columns outside the disk carry zero weight: w = 0 adds +0.0 to non-negative sums, which is
+// bit-identical to skipping the tap.
+// LDS: [lutrep lut_len*LUTREP f32][sw (r+1)*sw_len f32][tile (TH+2r) x TLW uint2]
+// Tile column X <-> image x = tile_x0 - r4 + X, stored at (X&3)*(TLW/4) + (X>>2).
+// ------------------------------------------------------------------------------------------
+template <int SCN, int TH, int LUTREP, bool CLAMP>
+__global__ __launch_bounds__(16 * TH) void jbf_tiled2_kernel(
+    const uint8_t *__restrict__ joint, const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
+    int h, int w, int jcn, int radius, int border, const float *__restrict__ lut, int lut_len,
+    const int *__restrict__ hwtab, const float *__restrict__ swsym, int sw_len, int tiles_x,
+    int tiles_per_img, int flags)
+{
+    constexpr int NT = 16 * TH;
+    constexpr int TLW = kTlw2;
+    constexpr int Q4 = TLW / 4;
+    extern __shared__ __align__(16) unsigned char smem[];
+    float *lutrep = reinterpret_cast<float *>(smem);
+    const int lut_bytes = (lut_len * LUTREP * 4 + 15) & ~15;
+    float *swl = reinterpret_cast<float *>(smem + lut_bytes);
+    const int sw_bytes = ((radius + 1) * sw_len * 4 + 15) & ~15;
+    uint2 *tile = reinterpret_cast<uint2 *>(smem + lut_bytes + sw_bytes);
+
+    const int tid = threadIdx.x;
+    const int img_idx = blockIdx.x / tiles_per_img;
+    const int t_in_img = blockIdx.x - img_idx * tiles_per_img;
+    const int tile_y0 = (t_in_img / tiles_x) * TH;
+    const int tile_x0 = (t_in_img % tiles_x) * kTileW;
+    const size_t img = (size_t)img_idx * h * w;
+    const int r4 = (radius + 3) & ~3;
+    const int tlh = TH + 2 * radius;
+
+    for (int i = tid; i < lut_len * LUTREP; i += NT)
+        lutrep[i] = lut[i / LUTREP];
+    for (int i = tid; i < (radius + 1) * sw_len; i += NT)
+        swl[i] = swsym[i];
+    const int tlw_used = kTileW + 2 * r4 + (kPix - 1) + 2;  // +2: pipeline look-ahead columns
+    for (int ry = tid >> 6; ry < tlh; ry += NT >> 6) {
+        const int gy = border_interpolate(tile_y0 - radius + ry, h, border);
+        for (int X = tid & 63; X < tlw_used; X += 64) {
+            const int gx = border_interpolate(tile_x0 - r4 + X, w, border);
+            uint2 t = make_uint2(0u, 0u);
+            if (gy >= 0 && gx >= 0) {
+                const size_t q = img + (size_t)gy * w + gx;
+                t.x = load_packed(joint, q, jcn);
+                t.y = load_packed(src, q, SCN);
+            }
+            tile[ry * TLW + (X & 3) * Q4 + (X >> 2)] = t;
+        }
+    }
+    __syncthreads();
+
+    const int tx = tid & 15;
+    const int ty = tid >> 4;
+    const uint32_t lane_lut = (uint32_t)(tid & (LUTREP - 1));
+    const uint32_t amax = (uint32_t)(lut_len - 1);
+
+    uint32_t jc[kPix];
+#pragma unroll
+    for (int p = 0; p < kPix; p++) {
+        const int X = 4 * tx + p + r4;
+        jc[p] = tile[(ty + radius) * TLW + (X & 3) * Q4 + (X >> 2)].x;
+    }
+    float sum[kPix][SCN];
+    float wsum[kPix];
+#pragma unroll
+    for (int p = 0; p < kPix; p++) {
+        wsum[p] = 0.f;
+#pragma unroll
+        for (int c = 0; c < SCN; c++)
+            sum[p][c] = 0.f;
+    }
+
+    // LDS byte addresses (dynamic LDS starts at offset 0 of the workgroup's allocation; the
+    // low 32 bits of a generic pointer into LDS are that offset)
+    const uint32_t lut_lane_addr =
+        static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lutrep)) + lane_lut * 4u;
+    const uint32_t sw_addr0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(swl));
+    const uint32_t tile_lane_addr =
+        static_cast<uint32_t>(reinterpret_cast<uintptr_t>(tile)) + (uint32_t)tx * 8u;
+
+    // The LDS reads of the tap loop are issued through asm so that their ORDER and the counted
+    // waits are exactly the 3-stage pipeline described above (the compiler otherwise sinks the
+    // reads next to their uses and waits for lgkmcnt(0) after every gather).  LDS returns in
+    // order, so "s_waitcnt lgkmcnt(N)" = everything but the N youngest reads has landed.  The
+    // wait statements name the registers they release as in/out operands: that is what keeps the
+    // compiler from scheduling a consumer above its wait.
+#define RF_LDS_READ_B64(dst, addr, off) \
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define RF_LDS_READ_B128(dst, addr, off) \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define RF_LDS_READ_B32(dst, addr) asm volatile("ds_read_b32 %0, %1" : "=v"(dst) : "v"(addr))
+#define RF_WAIT_TEXEL(n, t) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(t))
+#define RF_WAIT_GATHER(n, g) \
+    asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]))
+#define RF_WAIT_GATHER_W(n, g, wa, wb)                        \
+    asm volatile("s_waitcnt lgkmcnt(" #n ")"                   \
+                 : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]), "+v"(wa), "+v"(wb))
+
+    auto issue_gathers = [&](uint32_t jtex, float *g) {
+#pragma unroll
+        for (int p = 0; p < kPix; p++) {
+            uint32_t alpha = __builtin_amdgcn_sad_u8(jtex, jc[p], 0u);
+            if (CLAMP)
+                alpha = min(alpha, amax);
+            const uint32_t a = alpha * (LUTREP * 4u) + lut_lane_addr;
+            RF_LDS_READ_B32(g[p], a);
+        }
+    };
+
+    for (int i = -radius; i <= radius; i++) {
+        const int hw = hwtab[i + radius];
+        const int hw4 = (hw + 3) & ~3;
+        const int ai = i < 0 ? -i : i;
+        // column c = 4*gq + u - hw4 (gq = 0 .. hw4/2): tile column X = c + r4 + 4*tx, i.e. texel
+        // address = ta + u*Q4*8 + gq*8 with ta the per-lane address of (row, group 0, u = 0)
+        uint32_t ta = tile_lane_addr +
+                      (uint32_t)(((ty + i + radius) * TLW + ((r4 - hw4) >> 2)) * 8);
+        // weight of tap (i, j) = swc[j] = swc[-j]; group gq needs swc[hw4 - 4*gq - 4 .. +3]
+        uint32_t wa_addr = sw_addr0 + (uint32_t)((ai * sw_len + (r4 + 4) + hw4 - 4) * 4);
+        const int ngroups = (hw4 >> 1) + 1;
+
+        // Register rings with compile-time indices only: column 4*gq+u lives in tq[u], its
+        // gathers in gg[u & 1].  Every read issued in a step is released by the wait at the END
+        // of that step, so nothing is in flight across the loop back-edge (a value in flight
+        // there would be copied by the compiler's phi moves before it has landed).
+        uint2v tq[4];
+        float4v wna, wnb;
+        float gg[2][kPix];
+        RF_LDS_READ_B64(tq[0], ta, 0);
+        RF_LDS_READ_B64(tq[1], ta, Q4 * 8);
+        RF_LDS_READ_B128(wna, wa_addr, 0);
+        RF_LDS_READ_B128(wnb, wa_addr, 16);
+        RF_WAIT_TEXEL(3, tq[0]);
+        issue_gathers(tq[0].x, gg[0]);
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(tq[1]), "+v"(wna), "+v"(wnb), "+v"(gg[0][0]), "+v"(gg[0][1]),
+                       "+v"(gg[0][2]), "+v"(gg[0][3]));
+
+#define RF_ACCUM(U)                                                                  \
+    {                                                                                \
+        const uint32_t sv = tq[(U)].y;                                               \
+        float s[SCN];                                                                \
+        s[0] = (float)(sv & 0xff);                                                   \
+        if (SCN == 3) {                                                              \
+            s[1] = (float)((sv >> 8) & 0xff);                                        \
+            s[2] = (float)((sv >> 16) & 0xff);                                       \
+        }                                                                            \
+        _Pragma("unroll") for (int p = 0; p < kPix; p++)                             \
+        {                                                                            \
+            const float wgt = __fmul_rn(wv[4 + p - (U)], gg[(U) & 1][p]);            \
+            _Pragma("unroll") for (int ch = 0; ch < SCN; ch++) sum[p][ch] =          \
+                __fadd_rn(sum[p][ch], __fmul_rn(wgt, s[ch]));                        \
+            wsum[p] = __fadd_rn(wsum[p], wgt);                                       \
+        }                                                                            \
+    }
+#define RF_TEXEL_OFF(U) ((((U) + 2) & 3) * Q4 * 8 + (((U) + 2) >> 2) * 8)
+        // The accumulators are in/out operands of the end-of-step wait as well: that pins the
+        // accumulation of column k between the issue of the reads and their wait (LLVM otherwise
+        // sinks it below the wait and the reads overlap with nothing).
+#define RF_ACC_OPERANDS                                                                         \
+    "+v"(sum[0][0]), "+v"(sum[1][0]), "+v"(sum[2][0]), "+v"(sum[3][0]), "+v"(sum[0][SCN - 1]),  \
+        "+v"(sum[1][SCN - 1]), "+v"(sum[2][SCN - 1]), "+v"(sum[3][SCN - 1]),                    \
+        "+v"(sum[0][SCN / 2]), "+v"(sum[1][SCN / 2]), "+v"(sum[2][SCN / 2]),                    \
+        "+v"(sum[3][SCN / 2]), "+v"(wsum[0]), "+v"(wsum[1]), "+v"(wsum[2]), "+v"(wsum[3])
+        // one column: issue texel(+2) and gathers(+1), accumulate column +0 underneath them,
+        // then release what was issued
+#define RF_STEP(U)                                                                            \
+    RF_LDS_READ_B64(tq[((U) + 2) & 3], ta, RF_TEXEL_OFF(U));                                  \
+    issue_gathers(tq[((U) + 1) & 3].x, gg[((U) + 1) & 1]);                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+    RF_ACCUM(U)                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                       \
+                 : "+v"(tq[((U) + 2) & 3]), "+v"(gg[((U) + 1) & 1][0]),                       \
+                   "+v"(gg[((U) + 1) & 1][1]), "+v"(gg[((U) + 1) & 1][2]),                    \
+                   "+v"(gg[((U) + 1) & 1][3]), RF_ACC_OPERANDS);                              \
+    __builtin_amdgcn_sched_barrier(0);
+
+        for (int gq = 0; gq < ngroups; gq++) {
+            float wv[8];
+            wv[0] = wna.x; wv[1] = wna.y; wv[2] = wna.z; wv[3] = wna.w;
+            wv[4] = wnb.x; wv[5] = wnb.y; wv[6] = wnb.z; wv[7] = wnb.w;
+            RF_STEP(0)
+            RF_STEP(1)
+            RF_STEP(2)
+            // u = 3 also fetches the next group's weight window
+            RF_LDS_READ_B64(tq[1], ta, RF_TEXEL_OFF(3));
+            issue_gathers(tq[0].x, gg[0]);
+            wa_addr -= 16;
+            RF_LDS_READ_B128(wna, wa_addr, 0);
+            RF_LDS_READ_B128(wnb, wa_addr, 16);
+            __builtin_amdgcn_sched_barrier(0);
+            RF_ACCUM(3)
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(tq[1]), "+v"(wna), "+v"(wnb), "+v"(gg[0][0]), "+v"(gg[0][1]),
+                           "+v"(gg[0][2]), "+v"(gg[0][3]), RF_ACC_OPERANDS);
+            __builtin_amdgcn_sched_barrier(0);
+            ta += 8;
+        }
+#undef RF_STEP
+#undef RF_ACC_OPERANDS
+#undef RF_ACCUM
+#undef RF_TEXEL_OFF
+    }
+#undef RF_LDS_READ_B64
+#undef RF_LDS_READ_B128
+#undef RF_LDS_READ_B32
+#undef RF_WAIT_TEXEL
+#undef RF_WAIT_GATHER
+#undef RF_WAIT_GATHER_W
+
+    const int oy = tile_y0 + ty;
+    if (oy < h) {
+#pragma unroll
+        for (int p = 0; p < kPix; p++) {
+            const int ox = tile_x0 + 4 * tx + p;
+            if (ox < w)
+                finish_pixel(dst + (img + (size_t)oy * w + ox) * SCN, sum[p], wsum[p], SCN, flags);
+        }
+    }
+}
+
+struct Tiled2Config {
+    int th, lutrep;
+};
+
+size_t tiled2_lds_bytes(const JbfTables &t, int th, int lutrep)
+{
+    const size_t lut_bytes = ((size_t)t.lut_len * lutrep * 4 + 15) & ~(size_t)15;
+    const size_t sw_bytes = ((size_t)(t.radius + 1) * t.sw_len * 4 + 15) & ~(size_t)15;
+    return lut_bytes + sw_bytes + (size_t)kTlw2 * (th + 2 * t.radius) * sizeof(uint2);
+}
+
+template <int SCN, int TH, int LUTREP>
+int launch_tiled2(const JbfTables &t, const uint8_t *joint, const uint8_t *src, uint8_t *dst, int n,
+                  int h, int w, int jcn, int border, int flags, hipStream_t stream)
+{
+    const bool clamp = t.lut_len < 256 * jcn;
+    const size_t lds = tiled2_lds_bytes(t, TH, LUTREP);
+    const int tiles_x = ceil_div(w, kTileW), tiles_y = ceil_div(h, TH);
+    const long long blocks = (long long)tiles_x * tiles_y * n;
+    if (blocks > 0x7fffffffLL)
+        return fail(RF_E_UNSUPPORTED, "rf_jbf_u8: batch too large for one launch");
+    auto kern = clamp ? jbf_tiled2_kernel<SCN, TH, LUTREP, true>
+                      : jbf_tiled2_kernel<SCN, TH, LUTREP, false>;
+    RF_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(16 * TH), lds, stream, joint, src, dst, h,
+                       w, jcn, t.radius, border, t.d_lut, t.lut_len, t.d_hw, t.d_swsym, t.sw_len,
+                       tiles_x, tiles_x * tiles_y, flags);
+    return RF_OK;
+}
+
 int tiled_geometry(int radius, int lut_len, int *tlw, int *tlh, size_t *lds_bytes)
 {
     int wv = kTileW + 2 * radius + (kPix - 1);
@@ -356,10 +642,46 @@ extern "C" int rf_jbf_u8(const uint8_t *joint, const uint8_t *src, uint8_t *dst,
     if (rc != RF_OK)
         return rc;
 
+    // ---- kernel selection -------------------------------------------------------------
+    // tune = 0: automatic.  1: first-generation tiled kernel.  2..6: v2 with a fixed
+    // (tile height, LUT replicas) = (32,32) (32,16) (48,16) (48,8) (32,8).
+    const int tune = (flags >> RF_JBF_TUNE_SHIFT) & 0xf;
+    static const Tiled2Config kCfg[] = {{32, 32}, {32, 16}, {48, 16}, {48, 8}, {32, 8}};
+    static const int kAutoOrder[] = {0, 1, 4};
+    int cfg = -1;
+    const bool v2_radius_ok = t.r4 <= 36;
+    if (!(flags & RF_JBF_FORCE_GENERIC) && v2_radius_ok) {
+        if (tune >= 2 && tune <= 6) {
+            if (tiled2_lds_bytes(t, kCfg[tune - 2].th, kCfg[tune - 2].lutrep) <= (size_t)kMaxLds)
+                cfg = tune - 2;
+        } else if (tune == 0) {
+            for (int c : kAutoOrder)
+                if (tiled2_lds_bytes(t, kCfg[c].th, kCfg[c].lutrep) <= (size_t)kMaxLds) {
+                    cfg = c;
+                    break;
+                }
+        }
+    }
     int tlw = 0, tlh = 0;
     size_t lds = 0;
     const bool tiled_ok = tiled_geometry(radius, t.lut_len, &tlw, &tlh, &lds);
-    if (tiled_ok && !(flags & RF_JBF_FORCE_GENERIC)) {
+    if (cfg >= 0) {
+#define RF_T2(TH_, REP_)                                                                        \
+    rc = src_cn == 3 ? launch_tiled2<3, TH_, REP_>(t, joint, src, dst, n, h, w, joint_cn, border, \
+                                                   flags, stream)                               \
+                     : launch_tiled2<1, TH_, REP_>(t, joint, src, dst, n, h, w, joint_cn, border, \
+                                                   flags, stream)
+        switch (cfg) {
+        case 0: RF_T2(32, 32); break;
+        case 1: RF_T2(32, 16); break;
+        case 2: RF_T2(48, 16); break;
+        case 3: RF_T2(48, 8); break;
+        default: RF_T2(32, 8); break;
+        }
+#undef RF_T2
+        if (rc != RF_OK)
+            return rc;
+    } else if (tiled_ok && !(flags & RF_JBF_FORCE_GENERIC) && (tune == 0 || tune == 1)) {
         const int tiles_x = ceil_div(w, kTileW), tiles_y = ceil_div(h, kTileH);
         const long long blocks = (long long)tiles_x * tiles_y * n;
         if (blocks > 0x7fffffffLL)
