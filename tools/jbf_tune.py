@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--sigma-color", type=float, default=20.0)
     ap.add_argument("--sigma-spatial", type=float, default=22.0)
     ap.add_argument("--grey", action="store_true", help="src = joint = grey map (BF(CNN,CNN))")
+    ap.add_argument("--rgb-src", action="store_true", help="src = a second RGB scene")
     ap.add_argument("--libs", default="", help="comma-separated extra librf_hip builds to compare")
     args = ap.parse_args()
     import torch
@@ -35,6 +36,8 @@ def main():
     joint, src = bench.synth_batch(torch, args.batch, args.height, args.width, 4321, dev)
     if args.grey:
         joint = src.clone()
+    if args.rgb_src:
+        src = bench.synth_batch(torch, args.batch, args.height, args.width, 99, dev)[0]
     libs = [("default", _ffi.load_library())]
     for path in filter(None, args.libs.split(",")):
         lib = ctypes.CDLL(path)

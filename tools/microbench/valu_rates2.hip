@@ -1,0 +1,178 @@
+// valu_rates2.hip -- second microbenchmark round for the joint-bilateral tap loop (gfx950):
+// per-opcode issue cost of the integer/convert candidates, mixed streams, the shader clock
+// (s_memtime vs s_memrealtime) and the LDS out-of-range read behaviour.
+// Build: hipcc -O3 --offload-arch=gfx950 valu_rates2.hip -o valu_rates2.bin
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x)                                                           \
+    do {                                                                   \
+        hipError_t e = (x);                                                \
+        if (e != hipSuccess) {                                             \
+            fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e));         \
+            exit(1);                                                       \
+        }                                                                  \
+    } while (0)
+
+constexpr int kIters = 4096 * 32;
+
+#define OPS16(OP) OP(r0) OP(r1) OP(r2) OP(r3) OP(r4) OP(r5) OP(r6) OP(r7) OP(r0) OP(r1) OP(r2) OP(r3) OP(r4) OP(r5) OP(r6) OP(r7)
+
+#define KERNEL(NAME, ASM)                                                                  \
+    __global__ void NAME(unsigned *out, int iters, unsigned long long *clk)                \
+    {                                                                                      \
+        unsigned r0 = threadIdx.x * 2654435761u, r1 = r0 ^ 0x55, r2 = r0 + 77, r3 = r0 * 3, \
+                 r4 = r0 + 5, r5 = r0 ^ 9, r6 = r0 + 11, r7 = r0 * 7;                       \
+        const unsigned a = threadIdx.x | 0x01020304u, b = 0x3f800001u;                     \
+        unsigned long long t0 = __builtin_amdgcn_s_memtime();                              \
+        unsigned long long q0 = __builtin_amdgcn_s_memrealtime();                          \
+        for (int it = 0; it < iters; it++) {                                               \
+            OPS16(ASM)                                                                     \
+        }                                                                                  \
+        unsigned long long t1 = __builtin_amdgcn_s_memtime();                              \
+        unsigned long long q1 = __builtin_amdgcn_s_memrealtime();                          \
+        if (blockIdx.x == 0 && threadIdx.x == 0 && clk) {                                  \
+            clk[0] = t1 - t0;                                                              \
+            clk[1] = q1 - q0;                                                              \
+        }                                                                                  \
+        unsigned r = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7;                                \
+        if (r == 0x12345678u)                                                              \
+            out[threadIdx.x] = r;                                                          \
+    }
+
+#define A_MULF(x) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(x) : "v"(b));
+#define A_MULF_SGPR(x) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(x) : "s"(b));
+#define A_MULF_E64(x) asm volatile("v_mul_f32_e64 %0, %1, %0" : "+v"(x) : "v"(b));
+#define A_ADDF(x) asm volatile("v_add_f32 %0, %1, %0" : "+v"(x) : "v"(b));
+#define A_FMAC(x) asm volatile("v_fmac_f32 %0, %1, %1" : "+v"(x) : "v"(b));
+#define A_SAD(x) asm volatile("v_sad_u8 %0, %0, %1, 0" : "+v"(x) : "v"(a));
+#define A_SAD_ACC(x) asm volatile("v_sad_u8 %0, %0, %1, %1" : "+v"(x) : "v"(a));
+#define A_SAD16(x) asm volatile("v_sad_u16 %0, %0, %1, 0" : "+v"(x) : "v"(a));
+#define A_MIN(x) asm volatile("v_min_u32 %0, %1, %0" : "+v"(x) : "v"(a));
+#define A_LSHLADD(x) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(x) : "v"(a));
+#define A_LSHLREV(x) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(x));
+#define A_ADDU(x) asm volatile("v_add_u32 %0, %1, %0" : "+v"(x) : "v"(a));
+#define A_AND(x) asm volatile("v_and_b32 %0, %1, %0" : "+v"(x) : "v"(a));
+#define A_MULU24(x) asm volatile("v_mul_u32_u24 %0, %1, %0" : "+v"(x) : "v"(a));
+#define A_MADU24(x) asm volatile("v_mad_u32_u24 %0, %0, %1, %1" : "+v"(x) : "v"(a));
+#define A_CVTUB0(x) asm volatile("v_cvt_f32_ubyte0 %0, %0" : "+v"(x));
+#define A_CVTU32(x) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(x));
+#define A_MOV(x) asm volatile("v_mov_b32 %0, %1" : "=v"(x) : "v"(a));
+#define A_PERM(x) asm volatile("v_perm_b32 %0, %0, %1, %1" : "+v"(x) : "v"(a));
+#define A_BFE(x) asm volatile("v_bfe_u32 %0, %0, 8, 8" : "+v"(x));
+#define A_ADD3(x) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(x) : "v"(a));
+#define A_LSHLOR(x) asm volatile("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(x) : "v"(a));
+#define A_MIX_SAD_MUL(x) asm volatile("v_sad_u8 %0, %0, %1, 0\n v_mul_f32 %0, %2, %0" : "+v"(x) : "v"(a), "v"(b));
+#define A_MIX_SAD_3MUL(x) asm volatile("v_sad_u8 %0, %0, %1, 0\n v_mul_f32 %0, %2, %0\n v_add_f32 %0, %2, %0\n v_mul_f32 %0, %2, %0" : "+v"(x) : "v"(a), "v"(b));
+#define A_MIX_TAP(x) asm volatile("v_sad_u8 %0, %0, %1, 0\n v_lshl_add_u32 %0, %0, 1, %1\n v_mul_f32 %0, %2, %0\n v_mul_f32 %0, %2, %0\n v_add_f32 %0, %2, %0\n v_add_f32 %0, %2, %0" : "+v"(x) : "v"(a), "v"(b));
+
+KERNEL(k_mulf, A_MULF)
+KERNEL(k_mulf_sgpr, A_MULF_SGPR)
+KERNEL(k_mulf_e64, A_MULF_E64)
+KERNEL(k_addf, A_ADDF)
+KERNEL(k_fmac, A_FMAC)
+KERNEL(k_sad, A_SAD)
+KERNEL(k_sad_acc, A_SAD_ACC)
+KERNEL(k_sad16, A_SAD16)
+KERNEL(k_min, A_MIN)
+KERNEL(k_lshladd, A_LSHLADD)
+KERNEL(k_lshlrev, A_LSHLREV)
+KERNEL(k_addu, A_ADDU)
+KERNEL(k_and, A_AND)
+KERNEL(k_mulu24, A_MULU24)
+KERNEL(k_madu24, A_MADU24)
+KERNEL(k_cvtub0, A_CVTUB0)
+KERNEL(k_cvtu32, A_CVTU32)
+KERNEL(k_mov, A_MOV)
+KERNEL(k_perm, A_PERM)
+KERNEL(k_bfe, A_BFE)
+KERNEL(k_add3, A_ADD3)
+KERNEL(k_lshlor, A_LSHLOR)
+KERNEL(k_mix_sad_mul, A_MIX_SAD_MUL)
+KERNEL(k_mix_sad_3mul, A_MIX_SAD_3MUL)
+KERNEL(k_mix_tap, A_MIX_TAP)
+
+typedef void (*kern_t)(unsigned *, int, unsigned long long *);
+
+void run(const char *name, kern_t k, int instr_per_op, unsigned *d_out, unsigned long long *d_clk)
+{
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    for (int wps : {2, 4}) {
+        const int threads = 256 * wps > 1024 ? 1024 : 256 * wps;
+        const int blocks = 256 * ((256 * wps) / threads);
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(threads), 0, 0, d_out, kIters / 4, nullptr);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(threads), 0, 0, d_out, kIters, d_clk);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float ms = 0;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        unsigned long long clk[2];
+        CHECK(hipMemcpy(clk, d_clk, sizeof(clk), hipMemcpyDeviceToHost));
+        const double ghz = (double)clk[0] / ((double)clk[1] * 10.0);  // realtime ticks are 100 MHz
+        const double winstr = (double)kIters * 16 * instr_per_op;       // per wave
+        const double cyc_per_instr_simd = (double)clk[0] / winstr / wps; // shader cycles per wave-instr per SIMD
+        printf("%-26s waves/SIMD=%d %8.3f ms  clock %.3f GHz  %.2f cycles/wave-instr/SIMD\n", name, wps,
+               ms, ghz, cyc_per_instr_simd);
+    }
+}
+
+// LDS out-of-range probe: allocate all 160 KiB, read past the end.
+__global__ void lds_oob_kernel(unsigned *out)
+{
+    extern __shared__ unsigned lds[];
+    for (int i = threadIdx.x; i < 40960; i += blockDim.x)
+        lds[i] = 0xdeadbeefu;
+    __syncthreads();
+    unsigned v[6];
+    const unsigned addrs[6] = {163836u, 163840u, 163840u + 4u * threadIdx.x, 200000u, 1000000u,
+                               163840u + 65536u};
+    for (int k = 0; k < 6; k++)
+        asm volatile("ds_read_b32 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(v[k]) : "v"(addrs[k]));
+    if (threadIdx.x < 64)
+        for (int k = 0; k < 6; k++)
+            out[threadIdx.x * 6 + k] = v[k];
+}
+
+int main()
+{
+    unsigned *d_out;
+    unsigned long long *d_clk;
+    CHECK(hipMalloc(&d_out, 1 << 16));
+    CHECK(hipMalloc(&d_clk, 64));
+    for (int i = 0; i < 10; i++)
+        hipLaunchKernelGGL(k_fmac, dim3(1024), dim3(256), 0, 0, d_out, kIters, nullptr);
+    CHECK(hipDeviceSynchronize());
+#define RUN(k, n) run(#k, k, n, d_out, d_clk)
+    RUN(k_mulf, 1); RUN(k_mulf_sgpr, 1); RUN(k_mulf_e64, 1); RUN(k_addf, 1); RUN(k_fmac, 1);
+    RUN(k_sad, 1); RUN(k_sad_acc, 1); RUN(k_sad16, 1); RUN(k_min, 1); RUN(k_lshladd, 1);
+    RUN(k_lshlrev, 1); RUN(k_addu, 1); RUN(k_and, 1); RUN(k_mulu24, 1); RUN(k_madu24, 1);
+    RUN(k_cvtub0, 1); RUN(k_cvtu32, 1); RUN(k_mov, 1); RUN(k_perm, 1); RUN(k_bfe, 1);
+    RUN(k_add3, 1); RUN(k_lshlor, 1); RUN(k_mix_sad_mul, 2); RUN(k_mix_sad_3mul, 4);
+    RUN(k_mix_tap, 6);
+
+    CHECK(hipFuncSetAttribute((const void *)lds_oob_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+    hipLaunchKernelGGL(lds_oob_kernel, dim3(1), dim3(256), 163840, 0, d_out);
+    CHECK(hipDeviceSynchronize());
+    std::vector<unsigned> h(64 * 6);
+    CHECK(hipMemcpy(h.data(), d_out, h.size() * 4, hipMemcpyDeviceToHost));
+    printf("LDS OOB probe (alloc 163840 B): lane0 [last valid, +0, +4*lane, 200000, 1000000, +64K] = ");
+    for (int k = 0; k < 6; k++)
+        printf("%08x ", h[k]);
+    printf("\n lane 5: ");
+    for (int k = 0; k < 6; k++)
+        printf("%08x ", h[5 * 6 + k]);
+    int bad = 0;
+    for (int l = 0; l < 64; l++)
+        for (int k = 1; k < 6; k++)
+            bad += h[l * 6 + k] != 0;
+    printf("\n out-of-range reads returning non-zero: %d of %d\n", bad, 64 * 5);
+    return 0;
+}
