@@ -146,6 +146,10 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
+    px_local = float(n) * h * w * args.steps
+    px_total, t_max = sharding.reduce_job(px_local, elapsed, world, device=device)
+    kernel_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / max(1, args.steps)
+
     # secondary figure (not `value`): the same launch with a 3-channel colour src, which takes
     # the 3-channel accumulation path (the headline src is the grey CNN-style map the reference
     # filters, for which the kernel accumulates one channel and replicates it: identical bits)
@@ -160,10 +164,6 @@ def main():
         torch.cuda.synchronize()
         rgb_ms = e0.elapsed_time(e1)
         del src_rgb
-
-    px_local = float(n) * h * w * args.steps
-    px_total, t_max = sharding.reduce_job(px_local, elapsed, world, device=device)
-    kernel_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / max(1, args.steps)
 
     if rank != 0:
         return

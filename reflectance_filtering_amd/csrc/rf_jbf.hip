@@ -8,16 +8,12 @@
 // opencv_contrib/modules/ximgproc/src/joint_bilateral_filter.cpp on a non-FMA build.
 //
 // Kernels:
-//   jbf_tiled_kernel   one 512-thread workgroup = 64x32 output tile.  The joint/src tile with
-//                      its halo is staged once into LDS as packed {BGRx joint, BGRx src}
-//                      8-byte texels (border handling happens at staging time, so the tap
-//                      loop is branch-free), the colour LUT sits in LDS replicated 32x so that
-//                      every lane gathers from its own bank, each lane owns 4 horizontally
-//                      adjacent outputs and slides over the tap row so every LDS texel and
-//                      its 3 byte->float conversions feed 4 outputs.
+//   jbf_tiled2_kernel  one workgroup = 64 x TH output tile, software-pipelined LDS tap loop (see
+//                      the comment above jbf_tap_loop).
 //   jbf_generic_kernel untiled, any radius, global-memory gathers (fallback + cross-check).
 #include <cmath>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #include "rf_common.hpp"
@@ -26,10 +22,7 @@ namespace rf {
 namespace {
 
 constexpr int kTileW = 64;
-constexpr int kTileH = 32;
 constexpr int kPix = 4;        // outputs per lane (horizontal)
-constexpr int kThreads = 512;  // 16 lanes across x 32 rows
-constexpr int kLutRep = 32;    // LUT replicas = LDS banks of ds_read_b32
 constexpr int kMaxLds = 160 * 1024;
 constexpr int kTlw2 = 144;     // v2 tile row pitch in texels (covers radius <= 36)
 
@@ -43,13 +36,11 @@ struct JbfTables {
     double sigma_color = 0, sigma_space = 0;
     int maxk = 0;
     int lut_len = 0;   // entries kept: indices >= lut_len-1 are clamped (LUT value exactly 0)
-    int sw_stride = 0; // floats per padded spatial-weight row
     float *d_lut = nullptr;     // [256*joint_cn]
     int *d_di = nullptr;        // [maxk]
     int *d_dj = nullptr;        // [maxk]
     float *d_sw = nullptr;      // [maxk]
     int *d_hw = nullptr;        // [2r+1] half-width of the disk on tap row i
-    float *d_swpad = nullptr;   // [2r+1][sw_stride]: zeros | weights j=-hw..hw | zeros
     // v2: rows |i| = 0..r, each sw_len = 2*(r4+8) floats, centre at index r4+8, zeros outside
     // the disk (the weights are symmetric in i and in j)
     int r4 = 0, sw_len = 0;
@@ -66,7 +57,6 @@ void free_tables(JbfTables &t)
     (void)hipFree(t.d_dj);
     (void)hipFree(t.d_sw);
     (void)hipFree(t.d_hw);
-    (void)hipFree(t.d_swpad);
     (void)hipFree(t.d_swsym);
 }
 
@@ -104,8 +94,6 @@ int get_tables(int radius, int joint_cn, double sigma_color, double sigma_space,
     const int d = 2 * radius + 1;
     std::vector<int> di, dj, hw(d, -1);
     std::vector<float> sw;
-    t.sw_stride = d + 2 * (kPix - 1);
-    std::vector<float> swpad((size_t)d * t.sw_stride, 0.0f);
     for (int i = -radius; i <= radius; i++)
         for (int j = -radius; j <= radius; j++) {
             double r = std::sqrt((double)i * i + (double)j * j);
@@ -117,7 +105,6 @@ int get_tables(int radius, int joint_cn, double sigma_color, double sigma_space,
             sw.push_back(wgt);
             if (j >= 0 && j > hw[i + radius])
                 hw[i + radius] = j;
-            swpad[(size_t)(i + radius) * t.sw_stride + (j + radius + kPix - 1)] = wgt;
         }
     t.maxk = (int)di.size();
     t.r4 = (radius + 3) & ~3;
@@ -134,14 +121,11 @@ int get_tables(int radius, int joint_cn, double sigma_color, double sigma_space,
     RF_HIP_CHECK(hipMalloc(&t.d_dj, sizeof(int) * t.maxk));
     RF_HIP_CHECK(hipMalloc(&t.d_sw, sizeof(float) * t.maxk));
     RF_HIP_CHECK(hipMalloc(&t.d_hw, sizeof(int) * d));
-    RF_HIP_CHECK(hipMalloc(&t.d_swpad, sizeof(float) * swpad.size()));
     RF_HIP_CHECK(hipMemcpy(t.d_lut, lut.data(), sizeof(float) * nlut, hipMemcpyHostToDevice));
     RF_HIP_CHECK(hipMemcpy(t.d_di, di.data(), sizeof(int) * t.maxk, hipMemcpyHostToDevice));
     RF_HIP_CHECK(hipMemcpy(t.d_dj, dj.data(), sizeof(int) * t.maxk, hipMemcpyHostToDevice));
     RF_HIP_CHECK(hipMemcpy(t.d_sw, sw.data(), sizeof(float) * t.maxk, hipMemcpyHostToDevice));
     RF_HIP_CHECK(hipMemcpy(t.d_hw, hw.data(), sizeof(int) * d, hipMemcpyHostToDevice));
-    RF_HIP_CHECK(hipMemcpy(t.d_swpad, swpad.data(), sizeof(float) * swpad.size(),
-                           hipMemcpyHostToDevice));
     g_tables.push_back(t);
     *out = t;
     return RF_OK;
@@ -209,113 +193,6 @@ __global__ __launch_bounds__(256) void jbf_generic_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// Tiled kernel.
-// LDS: [ lutrep: lut_len*32 floats ][ tile: tlh rows x tlw texels of uint2 ]
-// Tile column X (0 = tile_x0 - radius) is stored at  (X & 3) * (tlw/4) + (X >> 2)  within its
-// row: the lane that owns outputs 4*tx..4*tx+3 reads X = 4*tx + const, i.e. consecutive lanes
-// read consecutive 8-byte texels (conflict-free ds_read_b64) although each lane's own outputs
-// are adjacent.  tlw % 32 == 16 keeps the two 16-lane rows of a 32-lane group on disjoint banks.
-// ------------------------------------------------------------------------------------------
-template <int SCN>
-__global__ __launch_bounds__(kThreads) void jbf_tiled_kernel(
-    const uint8_t *__restrict__ joint, const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
-    int h, int w, int jcn, int radius, int border, const float *__restrict__ lut, int lut_len,
-    const int *__restrict__ hwtab, const float *__restrict__ swpad, int sw_stride, int tlw,
-    int tlh, int tiles_x, int tiles_per_img, int flags)
-{
-    extern __shared__ __align__(16) unsigned char smem[];
-    float *lutrep = reinterpret_cast<float *>(smem);
-    uint2 *tile = reinterpret_cast<uint2 *>(smem + (size_t)lut_len * kLutRep * sizeof(float));
-
-    const int tid = threadIdx.x;
-    const int img_idx = blockIdx.x / tiles_per_img;
-    const int t_in_img = blockIdx.x - img_idx * tiles_per_img;
-    const int tile_y0 = (t_in_img / tiles_x) * kTileH;
-    const int tile_x0 = (t_in_img % tiles_x) * kTileW;
-    const size_t img = (size_t)img_idx * h * w;
-    const int q4 = tlw >> 2;
-
-    // ---- stage the colour LUT (replicated across banks) and the texel tile ----
-    for (int i = tid; i < lut_len * kLutRep; i += kThreads)
-        lutrep[i] = lut[i / kLutRep];
-    const int tlw_used = kTileW + 2 * radius + (kPix - 1);
-    for (int ry = tid >> 6; ry < tlh; ry += kThreads >> 6) {
-        const int gy = border_interpolate(tile_y0 - radius + ry, h, border);
-        for (int X = tid & 63; X < tlw_used; X += 64) {
-            const int gx = border_interpolate(tile_x0 - radius + X, w, border);
-            uint2 t = make_uint2(0u, 0u);
-            if (gy >= 0 && gx >= 0) {
-                const size_t q = img + (size_t)gy * w + gx;
-                t.x = load_packed(joint, q, jcn);
-                t.y = load_packed(src, q, SCN);
-            }
-            tile[ry * tlw + (X & 3) * q4 + (X >> 2)] = t;
-        }
-    }
-    __syncthreads();
-
-    const int tx = tid & 15;
-    const int ty = tid >> 4;
-    const int lane_lut = (tid & (kLutRep - 1));
-    const int amax = lut_len - 1;
-
-    // centre joint texels of this lane's 4 outputs: X = 4*tx + p + radius
-    uint32_t jc[kPix];
-#pragma unroll
-    for (int p = 0; p < kPix; p++) {
-        const int X = 4 * tx + p + radius;
-        jc[p] = tile[(ty + radius) * tlw + (X & 3) * q4 + (X >> 2)].x;
-    }
-    float sum[kPix][SCN];
-    float wsum[kPix];
-#pragma unroll
-    for (int p = 0; p < kPix; p++) {
-        wsum[p] = 0.f;
-#pragma unroll
-        for (int c = 0; c < SCN; c++)
-            sum[p][c] = 0.f;
-    }
-
-    for (int i = -radius; i <= radius; i++) {
-        const int hw = hwtab[i + radius];
-        const uint2 *trow = tile + (ty + i + radius) * tlw + tx;
-        // swr[j] = spatial weight of tap (i, j); zero for hw < |j| <= hw + 3
-        const float *swr = swpad + (size_t)(i + radius) * sw_stride + (radius + kPix - 1);
-        for (int c = -hw; c <= hw + kPix - 1; c++) {
-            const int cc = c + radius;  // uniform, >= 0
-            const uint2 t = trow[(cc & 3) * q4 + (cc >> 2)];
-            float s[SCN];
-            s[0] = (float)(t.y & 0xff);
-            if (SCN == 3) {
-                s[1] = (float)((t.y >> 8) & 0xff);
-                s[2] = (float)((t.y >> 16) & 0xff);
-            }
-#pragma unroll
-            for (int p = 0; p < kPix; p++) {
-                uint32_t alpha = __builtin_amdgcn_sad_u8(t.x, jc[p], 0u);
-                alpha = min(alpha, (uint32_t)amax);
-                const float wgt = __fmul_rn(swr[c - p], lutrep[alpha * kLutRep + lane_lut]);
-#pragma unroll
-                for (int ch = 0; ch < SCN; ch++)
-                    sum[p][ch] = __fadd_rn(sum[p][ch], __fmul_rn(wgt, s[ch]));
-                wsum[p] = __fadd_rn(wsum[p], wgt);
-            }
-        }
-    }
-
-    const int oy = tile_y0 + ty;
-    if (oy < h) {
-#pragma unroll
-        for (int p = 0; p < kPix; p++) {
-            const int ox = tile_x0 + 4 * tx + p;
-            if (ox < w)
-                finish_pixel(dst + (img + (size_t)oy * w + ox) * SCN, sum[p], wsum[p], SCN, flags);
-        }
-    }
-}
-
-
-// ------------------------------------------------------------------------------------------
 // Tiled kernel, software-pipelined (v2).
 //
 // Same tile idea as above, plus:
@@ -330,9 +207,21 @@ __global__ __launch_bounds__(kThreads) void jbf_tiled_kernel(
 //   * LUTREP replicas of the colour LUT (32 = conflict-free, 16/8 trade conflicts for LDS).
 // Columns outside the disk carry zero weight: w = 0 adds +0.0 to non-negative sums, which is
 // bit-identical to skipping the tap.
-// LDS: [lutrep lut_len*LUTREP f32][sw (r+1)*sw_len f32][tile (TH+2r) x TLW uint2]
+// LDS: [flag][lutrep lut_len*LUTREP f32][sw (r+1)*sw_len f32][tile (TH+2r) x TLW uint2]
 // Tile column X <-> image x = tile_x0 - r4 + X, stored at (X&3)*(TLW/4) + (X>>2).
 // ------------------------------------------------------------------------------------------
+// Block-wide AND of a predicate through one word of the caller's dynamic LDS (HIP's
+// __syncthreads_and brings 256 bytes of static LDS with it, which the kernels below cannot spare
+// and which would move the end of the allocation the LUT is aligned to).  `word` must have been
+// set to 1 before an earlier barrier.  Contains a barrier.
+__device__ inline int block_all(int pred, volatile int *word)
+{
+    if (!pred)
+        *word = 0;
+    __syncthreads();
+    return *word;
+}
+
 // LDS byte address of a pointer into the workgroup's LDS (low 32 bits of the generic pointer).
 __device__ inline uint32_t lds_addr(const void *p)
 {
@@ -349,18 +238,31 @@ __device__ inline uint32_t lds_addr(const void *p)
 #define RF_LDS_READ_B128(dst, addr, off) \
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 #define RF_LDS_READ_B32(dst, addr) asm volatile("ds_read_b32 %0, %1" : "=v"(dst) : "v"(addr))
+#define RF_LDS_READ_B32_OFF(dst, addr, off) \
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 
 // Accumulates all taps of one lane's 4 outputs.  NCH = channels accumulated (3, or 1 when the
 // src is single-channel or every src texel of the tile is grey: identical bits, a third of the
-// multiply-adds).  sum/wsum must be zero on entry.
-template <int NCH, int LUTREP, bool CLAMP, int TLW>
+// multiply-adds).  TB = bytes per LDS texel: 8 = {BGRx joint, BGRx src}; 4 = {B,G,R joint, grey
+// src} (NCH = 1 only).  CLAMP = clamp the LUT index with v_min (otherwise the caller guarantees
+// that every reachable index is either inside the staged table or beyond the end of the
+// workgroup's LDS allocation, where ds_read returns 0).  sum/wsum must be zero on entry.
+template <int NCH, int LUTREP, bool CLAMP, int TLW, int TB>
 __device__ __forceinline__ void jbf_tap_loop(uint32_t lut_lane_addr, uint32_t sw_addr0,
                                              uint32_t tile_lane_addr, const uint32_t (&jc)[kPix],
                                              uint32_t amax, int ty, int radius, int r4, int sw_len,
                                              const int *__restrict__ hwtab, float (&sum)[kPix][NCH],
                                              float (&wsum)[kPix])
 {
+    static_assert(TB == 8 || (TB == 4 && NCH == 1), "4-byte texels carry one src channel");
     constexpr int Q4 = TLW / 4;
+    using texel_t = typename std::conditional<TB == 8, uint2v, uint32_t>::type;
+    auto joint_of = [](const texel_t &t) -> uint32_t {
+        if constexpr (TB == 8)
+            return t.x;
+        else
+            return t & 0x00ffffffu;
+    };
     auto issue_gathers = [&](uint32_t jtex, float *g) {
 #pragma unroll
         for (int p = 0; p < kPix; p++) {
@@ -371,15 +273,21 @@ __device__ __forceinline__ void jbf_tap_loop(uint32_t lut_lane_addr, uint32_t sw
             RF_LDS_READ_B32(g[p], a);
         }
     };
+#define RF_READ_TEXEL(dst, addr, off_texels)          \
+    if constexpr (TB == 8) {                          \
+        RF_LDS_READ_B64(dst, addr, (off_texels) * 8); \
+    } else {                                          \
+        RF_LDS_READ_B32_OFF(dst, addr, (off_texels) * 4); \
+    }
 
     for (int i = -radius; i <= radius; i++) {
         const int hw = hwtab[i + radius];
         const int hw4 = (hw + 3) & ~3;
         const int ai = i < 0 ? -i : i;
         // column c = 4*gq + u - hw4 (gq = 0 .. hw4/2): tile column X = c + r4 + 4*tx, i.e. texel
-        // address = ta + u*Q4*8 + gq*8 with ta the per-lane address of (row, group 0, u = 0)
+        // address = ta + (u*Q4 + gq)*TB with ta the per-lane address of (row, group 0, u = 0)
         uint32_t ta = tile_lane_addr +
-                      (uint32_t)(((ty + i + radius) * TLW + ((r4 - hw4) >> 2)) * 8);
+                      (uint32_t)(((ty + i + radius) * TLW + ((r4 - hw4) >> 2)) * TB);
         // weight of tap (i, j) = swc[j] = swc[-j]; group gq needs swc[hw4 - 4*gq - 4 .. +3]
         uint32_t wa_addr = sw_addr0 + (uint32_t)((ai * sw_len + (r4 + 8) + hw4 - 4) * 4);
         const int ngroups = (hw4 >> 1) + 1;
@@ -388,27 +296,31 @@ __device__ __forceinline__ void jbf_tap_loop(uint32_t lut_lane_addr, uint32_t sw
         // gathers in gg[u & 1].  Every read issued in a step is released by the wait at the END
         // of that step, so nothing is in flight across the loop back-edge (a value in flight
         // there would be copied by the compiler's phi moves before it has landed).
-        uint2v tq[4];
+        texel_t tq[4];
         float4v wna, wnb;
         float gg[2][kPix];
-        RF_LDS_READ_B64(tq[0], ta, 0);
-        RF_LDS_READ_B64(tq[1], ta, Q4 * 8);
+        RF_READ_TEXEL(tq[0], ta, 0)
+        RF_READ_TEXEL(tq[1], ta, Q4)
         RF_LDS_READ_B128(wna, wa_addr, 0);
         RF_LDS_READ_B128(wnb, wa_addr, 16);
         asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(tq[0]));
-        issue_gathers(tq[0].x, gg[0]);
+        issue_gathers(joint_of(tq[0]), gg[0]);
         asm volatile("s_waitcnt lgkmcnt(0)"
                      : "+v"(tq[1]), "+v"(wna), "+v"(wnb), "+v"(gg[0][0]), "+v"(gg[0][1]),
                        "+v"(gg[0][2]), "+v"(gg[0][3]));
 
 #define RF_ACCUM(U)                                                                  \
     {                                                                                \
-        const uint32_t sv = tq[(U)].y;                                               \
         float s[NCH];                                                                \
-        s[0] = (float)(sv & 0xff);                                                   \
-        if (NCH == 3) {                                                              \
-            s[1] = (float)((sv >> 8) & 0xff);                                        \
-            s[2] = (float)((sv >> 16) & 0xff);                                       \
+        if constexpr (TB == 8) {                                                     \
+            const uint32_t sv = tq[(U)].y;                                           \
+            s[0] = (float)(sv & 0xff);                                               \
+            if constexpr (NCH == 3) {                                                \
+                s[1] = (float)((sv >> 8) & 0xff);                                    \
+                s[2] = (float)((sv >> 16) & 0xff);                                   \
+            }                                                                        \
+        } else {                                                                     \
+            s[0] = (float)(tq[(U)] >> 24);                                           \
         }                                                                            \
         _Pragma("unroll") for (int p = 0; p < kPix; p++)                             \
         {                                                                            \
@@ -418,7 +330,7 @@ __device__ __forceinline__ void jbf_tap_loop(uint32_t lut_lane_addr, uint32_t sw
             wsum[p] = __fadd_rn(wsum[p], wgt);                                       \
         }                                                                            \
     }
-#define RF_TEXEL_OFF(U) ((((U) + 2) & 3) * Q4 * 8 + (((U) + 2) >> 2) * 8)
+#define RF_TEXEL_OFF(U) ((((U) + 2) & 3) * Q4 + (((U) + 2) >> 2))
         // Pins the accumulators at this point of the instruction stream (no instruction).
 #define RF_PIN_ACC()                                                                            \
     if constexpr (NCH == 3) {                                                                   \
@@ -436,8 +348,8 @@ __device__ __forceinline__ void jbf_tap_loop(uint32_t lut_lane_addr, uint32_t sw
         // one column: issue texel(+2) and gathers(+1), accumulate column +0 underneath them,
         // then release what was issued
 #define RF_STEP(U)                                                                            \
-    RF_LDS_READ_B64(tq[((U) + 2) & 3], ta, RF_TEXEL_OFF(U));                                  \
-    issue_gathers(tq[((U) + 1) & 3].x, gg[((U) + 1) & 1]);                                    \
+    RF_READ_TEXEL(tq[((U) + 2) & 3], ta, RF_TEXEL_OFF(U))                                     \
+    issue_gathers(joint_of(tq[((U) + 1) & 3]), gg[((U) + 1) & 1]);                            \
     __builtin_amdgcn_sched_barrier(0);                                                        \
     RF_ACCUM(U)                                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                        \
@@ -457,8 +369,8 @@ __device__ __forceinline__ void jbf_tap_loop(uint32_t lut_lane_addr, uint32_t sw
             RF_STEP(1)
             RF_STEP(2)
             // u = 3 also fetches the next group's weight window
-            RF_LDS_READ_B64(tq[1], ta, RF_TEXEL_OFF(3));
-            issue_gathers(tq[0].x, gg[0]);
+            RF_READ_TEXEL(tq[1], ta, RF_TEXEL_OFF(3))
+            issue_gathers(joint_of(tq[0]), gg[0]);
             wa_addr -= 16;
             RF_LDS_READ_B128(wna, wa_addr, 0);
             RF_LDS_READ_B128(wnb, wa_addr, 16);
@@ -471,160 +383,21 @@ __device__ __forceinline__ void jbf_tap_loop(uint32_t lut_lane_addr, uint32_t sw
                          : "+v"(tq[1]), "+v"(wna), "+v"(wnb), "+v"(gg[0][0]), "+v"(gg[0][1]),
                            "+v"(gg[0][2]), "+v"(gg[0][3]));
             __builtin_amdgcn_sched_barrier(0);
-            ta += 8;
+            ta += TB;
         }
 #undef RF_STEP
 #undef RF_PIN_ACC
 #undef RF_ACCUM
 #undef RF_TEXEL_OFF
     }
-}
-
-// Same contract as jbf_tap_loop, deeper pipeline: one step = TWO columns.  While columns
-// (2s, 2s+1) are accumulated, the 8 LUT gathers of columns (2s+2, 2s+3) and the texels of
-// columns (2s+4, 2s+5) are in flight; all of them are released at the end of the step.  One loop
-// trip = 8 columns = two 4-column weight groups.  (With one column per step the accumulation
-// is shorter than an LDS round trip at 2 waves/SIMD and the loop is latency-bound.)
-template <int NCH, int LUTREP, bool CLAMP, int TLW>
-__device__ __forceinline__ void jbf_tap_loop_pairs(uint32_t lut_lane_addr, uint32_t sw_addr0,
-                                                   uint32_t tile_lane_addr,
-                                                   const uint32_t (&jc)[kPix], uint32_t amax, int ty,
-                                                   int radius, int r4, int sw_len,
-                                                   const int *__restrict__ hwtab,
-                                                   float (&sum)[kPix][NCH], float (&wsum)[kPix])
-{
-    constexpr int Q4 = TLW / 4;
-    auto issue_gathers = [&](uint32_t jtex, float *g) {
-#pragma unroll
-        for (int p = 0; p < kPix; p++) {
-            uint32_t alpha = __builtin_amdgcn_sad_u8(jtex, jc[p], 0u);
-            if (CLAMP)
-                alpha = min(alpha, amax);
-            const uint32_t a = alpha * (LUTREP * 4u) + lut_lane_addr;
-            RF_LDS_READ_B32(g[p], a);
-        }
-    };
-    // byte offset of body column cb (0..11) from the body's base texel address
-#define RF_COL_OFF(cb) ((((cb) & 3) * Q4 + ((cb) >> 2)) * 8)
-
-    for (int i = -radius; i <= radius; i++) {
-        const int hw = hwtab[i + radius];
-        const int hw4 = (hw + 3) & ~3;
-        const int ai = i < 0 ? -i : i;
-        uint32_t ta = tile_lane_addr +
-                      (uint32_t)(((ty + i + radius) * TLW + ((r4 - hw4) >> 2)) * 8);
-        // group gq (4 columns) needs swc[hw4 - 4*gq - 4 .. +3]; a body holds groups 2b, 2b+1
-        uint32_t wa_addr = sw_addr0 + (uint32_t)((ai * sw_len + (r4 + 8) + hw4 - 4) * 4);
-        const int nbodies = ((hw4 >> 1) + 2) >> 1;
-
-        uint2v tq[8];       // texel of body column cb lives in tq[cb & 7]
-        float gg[2][2][kPix];  // gathers of pair s live in gg[s & 1][column in pair]
-        // weight windows of the body's two groups overlap: group 2b uses (wf1, wf2), group
-        // 2b+1 uses (wf0, wf1); wf0 starts 4 floats below the first group's window
-        float4v wf0, wf1, wf2;
-        RF_LDS_READ_B64(tq[0], ta, RF_COL_OFF(0));
-        RF_LDS_READ_B64(tq[1], ta, RF_COL_OFF(1));
-        RF_LDS_READ_B64(tq[2], ta, RF_COL_OFF(2));
-        RF_LDS_READ_B64(tq[3], ta, RF_COL_OFF(3));
-        wa_addr -= 16;
-        RF_LDS_READ_B128(wf0, wa_addr, 0);
-        RF_LDS_READ_B128(wf1, wa_addr, 16);
-        RF_LDS_READ_B128(wf2, wa_addr, 32);
-        asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(tq[0]), "+v"(tq[1]));
-        issue_gathers(tq[0].x, gg[0][0]);
-        issue_gathers(tq[1].x, gg[0][1]);
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(tq[2]), "+v"(tq[3]), "+v"(wf0), "+v"(wf1), "+v"(wf2),
-                       "+v"(gg[0][0][0]), "+v"(gg[0][0][1]), "+v"(gg[0][0][2]), "+v"(gg[0][0][3]),
-                       "+v"(gg[0][1][0]), "+v"(gg[0][1][1]), "+v"(gg[0][1][2]), "+v"(gg[0][1][3]));
-
-#define RF_ACCUM_COL(CB, G)                                                          \
-    {                                                                                \
-        const uint32_t sv = tq[(CB) & 7].y;                                          \
-        float s[NCH];                                                                \
-        s[0] = (float)(sv & 0xff);                                                   \
-        if (NCH == 3) {                                                              \
-            s[1] = (float)((sv >> 8) & 0xff);                                        \
-            s[2] = (float)((sv >> 16) & 0xff);                                       \
-        }                                                                            \
-        _Pragma("unroll") for (int p = 0; p < kPix; p++)                             \
-        {                                                                            \
-            const float wgt = __fmul_rn(wv[(CB) >> 2][4 + p - ((CB) & 3)], (G)[p]);  \
-            _Pragma("unroll") for (int ch = 0; ch < NCH; ch++) sum[p][ch] =          \
-                __fadd_rn(sum[p][ch], __fmul_rn(wgt, s[ch]));                        \
-            wsum[p] = __fadd_rn(wsum[p], wgt);                                       \
-        }                                                                            \
-    }
-        // Pins the accumulators at this point of the instruction stream (no instruction).
-#define RF_PIN_ACC()                                                                            \
-    if constexpr (NCH == 3) {                                                                   \
-        asm volatile(""                                                                         \
-                     : "+v"(sum[0][0]), "+v"(sum[1][0]), "+v"(sum[2][0]), "+v"(sum[3][0]),      \
-                       "+v"(sum[0][1]), "+v"(sum[1][1]), "+v"(sum[2][1]), "+v"(sum[3][1]),      \
-                       "+v"(sum[0][NCH - 1]), "+v"(sum[1][NCH - 1]), "+v"(sum[2][NCH - 1]),     \
-                       "+v"(sum[3][NCH - 1]), "+v"(wsum[0]), "+v"(wsum[1]), "+v"(wsum[2]),      \
-                       "+v"(wsum[3]));                                                          \
-    } else {                                                                                    \
-        asm volatile(""                                                                         \
-                     : "+v"(sum[0][0]), "+v"(sum[1][0]), "+v"(sum[2][0]), "+v"(sum[3][0]),      \
-                       "+v"(wsum[0]), "+v"(wsum[1]), "+v"(wsum[2]), "+v"(wsum[3]));             \
-    }
-        // pair-step S (0..3): accumulate body columns 2S, 2S+1; gathers of 2S+2, 2S+3; texels
-        // of 2S+4, 2S+5
-#define RF_PAIR_ISSUE(S)                                                                      \
-    RF_LDS_READ_B64(tq[(2 * (S) + 4) & 7], ta, RF_COL_OFF(2 * (S) + 4));                      \
-    RF_LDS_READ_B64(tq[(2 * (S) + 5) & 7], ta, RF_COL_OFF(2 * (S) + 5));                      \
-    issue_gathers(tq[(2 * (S) + 2) & 7].x, gg[((S) + 1) & 1][0]);                             \
-    issue_gathers(tq[(2 * (S) + 3) & 7].x, gg[((S) + 1) & 1][1]);
-#define RF_PAIR_ACCUM(S)                                                                      \
-    __builtin_amdgcn_sched_barrier(0);                                                        \
-    RF_ACCUM_COL(2 * (S), gg[(S) & 1][0])                                                     \
-    RF_ACCUM_COL(2 * (S) + 1, gg[(S) & 1][1])                                                 \
-    __builtin_amdgcn_sched_barrier(0);                                                        \
-    RF_PIN_ACC()                                                                              \
-    __builtin_amdgcn_sched_barrier(0);
-#define RF_PAIR_WAIT(S)                                                                       \
-    asm volatile("s_waitcnt lgkmcnt(0)"                                                       \
-                 : "+v"(tq[(2 * (S) + 4) & 7]), "+v"(tq[(2 * (S) + 5) & 7]),                  \
-                   "+v"(gg[((S) + 1) & 1][0][0]), "+v"(gg[((S) + 1) & 1][0][1]),              \
-                   "+v"(gg[((S) + 1) & 1][0][2]), "+v"(gg[((S) + 1) & 1][0][3]),              \
-                   "+v"(gg[((S) + 1) & 1][1][0]), "+v"(gg[((S) + 1) & 1][1][1]),              \
-                   "+v"(gg[((S) + 1) & 1][1][2]), "+v"(gg[((S) + 1) & 1][1][3]));             \
-    __builtin_amdgcn_sched_barrier(0);
-
-        for (int b = 0; b < nbodies; b++) {
-            float wv[2][8];
-            wv[0][0] = wf1.x; wv[0][1] = wf1.y; wv[0][2] = wf1.z; wv[0][3] = wf1.w;
-            wv[0][4] = wf2.x; wv[0][5] = wf2.y; wv[0][6] = wf2.z; wv[0][7] = wf2.w;
-            wv[1][0] = wf0.x; wv[1][1] = wf0.y; wv[1][2] = wf0.z; wv[1][3] = wf0.w;
-            wv[1][4] = wf1.x; wv[1][5] = wf1.y; wv[1][6] = wf1.z; wv[1][7] = wf1.w;
-            RF_PAIR_ISSUE(0) RF_PAIR_ACCUM(0) RF_PAIR_WAIT(0)
-            RF_PAIR_ISSUE(1) RF_PAIR_ACCUM(1) RF_PAIR_WAIT(1)
-            RF_PAIR_ISSUE(2) RF_PAIR_ACCUM(2) RF_PAIR_WAIT(2)
-            // last pair of the body: also fetch the next body's two weight windows
-            RF_PAIR_ISSUE(3)
-            wa_addr -= 32;
-            RF_LDS_READ_B128(wf0, wa_addr, 0);
-            RF_LDS_READ_B128(wf1, wa_addr, 16);
-            RF_LDS_READ_B128(wf2, wa_addr, 32);
-            RF_PAIR_ACCUM(3)
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf0), "+v"(wf1), "+v"(wf2));
-            RF_PAIR_WAIT(3)
-            ta += 16;
-        }
-#undef RF_PAIR_ISSUE
-#undef RF_PAIR_ACCUM
-#undef RF_PAIR_WAIT
-#undef RF_PIN_ACC
-#undef RF_ACCUM_COL
-    }
-#undef RF_COL_OFF
+#undef RF_READ_TEXEL
 }
 #undef RF_LDS_READ_B64
 #undef RF_LDS_READ_B128
 #undef RF_LDS_READ_B32
+#undef RF_LDS_READ_B32_OFF
 
-template <int SCN, int TH, int LUTREP, bool CLAMP, bool PAIRS>
+template <int SCN, int TH, int LUTREP, bool CLAMP>
 __global__ __launch_bounds__(16 * TH) void jbf_tiled2_kernel(
     const uint8_t *__restrict__ joint, const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
     int h, int w, int jcn, int radius, int border, const float *__restrict__ lut, int lut_len,
@@ -635,11 +408,15 @@ __global__ __launch_bounds__(16 * TH) void jbf_tiled2_kernel(
     constexpr int TLW = kTlw2;
     constexpr int Q4 = TLW / 4;
     extern __shared__ __align__(16) unsigned char smem[];
-    float *lutrep = reinterpret_cast<float *>(smem);
+    volatile int *flag_word = reinterpret_cast<volatile int *>(smem);
+    float *lutrep = reinterpret_cast<float *>(smem + 16);
     const int lut_bytes = (lut_len * LUTREP * 4 + 15) & ~15;
-    float *swl = reinterpret_cast<float *>(smem + lut_bytes);
+    float *swl = reinterpret_cast<float *>(smem + 16 + lut_bytes);
     const int sw_bytes = ((radius + 1) * sw_len * 4 + 15) & ~15;
-    uint2 *tile = reinterpret_cast<uint2 *>(smem + lut_bytes + sw_bytes);
+    uint2 *tile = reinterpret_cast<uint2 *>(smem + 16 + lut_bytes + sw_bytes);
+    if (threadIdx.x == 0)
+        *flag_word = 1;
+    __syncthreads();
 
     const int tid = threadIdx.x;
     const int img_idx = blockIdx.x / tiles_per_img;
@@ -671,7 +448,9 @@ __global__ __launch_bounds__(16 * TH) void jbf_tiled2_kernel(
             tile[ry * TLW + (X & 3) * Q4 + (X >> 2)] = t;
         }
     }
-    const int all_grey = __syncthreads_and(grey);  // also the barrier that publishes the tile
+    const int all_grey = block_all(grey, flag_word);  // also the barrier that publishes the tile
+    if (flags & 0x1000)  // benchmark aid: staging only (tools/jbf_tune.py --stage-only)
+        return;
 
     const int tx = tid & 15;
     const int ty = tid >> 4;
@@ -697,13 +476,8 @@ __global__ __launch_bounds__(16 * TH) void jbf_tiled2_kernel(
             sum[p][c] = 0.f;
     }
     if (SCN == 3 && !all_grey) {
-        if (PAIRS)
-            jbf_tap_loop_pairs<SCN, LUTREP, CLAMP, TLW>(lut_lane_addr, sw_addr0, tile_lane_addr,
-                                                        jc, amax, ty, radius, r4, sw_len, hwtab,
-                                                        sum, wsum);
-        else
-            jbf_tap_loop<SCN, LUTREP, CLAMP, TLW>(lut_lane_addr, sw_addr0, tile_lane_addr, jc,
-                                                  amax, ty, radius, r4, sw_len, hwtab, sum, wsum);
+        jbf_tap_loop<SCN, LUTREP, CLAMP, TLW, 8>(lut_lane_addr, sw_addr0, tile_lane_addr, jc, amax,
+                                              ty, radius, r4, sw_len, hwtab, sum, wsum);
     } else {
         // single-channel accumulation; for a grey 3-channel src the three sums are the same
         // sequence of float operations, so replicating one of them is bit-identical
@@ -711,13 +485,8 @@ __global__ __launch_bounds__(16 * TH) void jbf_tiled2_kernel(
 #pragma unroll
         for (int p = 0; p < kPix; p++)
             sum1[p][0] = 0.f;
-        if (PAIRS)
-            jbf_tap_loop_pairs<1, LUTREP, CLAMP, TLW>(lut_lane_addr, sw_addr0, tile_lane_addr, jc,
-                                                      amax, ty, radius, r4, sw_len, hwtab, sum1,
-                                                      wsum);
-        else
-            jbf_tap_loop<1, LUTREP, CLAMP, TLW>(lut_lane_addr, sw_addr0, tile_lane_addr, jc, amax,
-                                                ty, radius, r4, sw_len, hwtab, sum1, wsum);
+        jbf_tap_loop<1, LUTREP, CLAMP, TLW, 8>(lut_lane_addr, sw_addr0, tile_lane_addr, jc, amax, ty,
+                                            radius, r4, sw_len, hwtab, sum1, wsum);
 #pragma unroll
         for (int p = 0; p < kPix; p++)
 #pragma unroll
@@ -736,10 +505,198 @@ __global__ __launch_bounds__(16 * TH) void jbf_tiled2_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// 64x64-tile kernel (1024 threads = 4 waves/SIMD), the default for radius <= 36.
+//
+// One launch shape serves both kinds of src; each tile decides for itself while staging:
+//   * grey src (single-channel src, or every src texel of the tile has B = G = R -- the case of
+//     the reference's `-r.png`): the tile is staged as 4-byte texels {B,G,R joint, grey src}.
+//     That halves the tile (130 rows x 144 x 4 B = 73 KB), which is what lets a 64-row tile, a
+//     32x replicated (conflict-free) LUT and the weight table share 160 KB of LDS, i.e. what
+//     buys 4 waves per SIMD.  All 1024 threads run the single-channel loop.
+//   * colour src: the tile is processed as two 32-row halves with 8-byte texels (98 x 144 x 8 B)
+//     and a 16x LUT; threads 0..511 run the 3-channel loop for each half, the others help stage.
+// The colour LUT sits at the END of the workgroup's 163,840-byte LDS allocation and holds only
+// the entries before its zero tail: an index past the table addresses LDS beyond the
+// allocation, where ds_read returns 0 -- exactly the LUT value there -- so the per-tap clamp
+// disappears.  rf_jbf_u8 verifies that behaviour once per device with a probe kernel and uses
+// the clamping kernel above if it ever does not hold.
+// LDS: [flag][sw table][tile ...                   free ...][LUT nz*REP f32] = 163,840 B
+// ------------------------------------------------------------------------------------------
+constexpr int kT64Lds = 163840;
+
+template <int SCN, int GREP, int CREP>
+__global__ __launch_bounds__(1024) void jbf_tile64_kernel(
+    const uint8_t *__restrict__ joint, const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
+    int h, int w, int jcn, int radius, int border, const float *__restrict__ lut, int nz,
+    const int *__restrict__ hwtab, const float *__restrict__ swsym, int sw_len, int tiles_x,
+    int tiles_per_img, int flags)
+{
+    constexpr int NT = 1024;
+    constexpr int TLW = kTlw2;
+    constexpr int Q4 = TLW / 4;
+    extern __shared__ __align__(16) unsigned char smem[];
+    volatile int *flag_word = reinterpret_cast<volatile int *>(smem);
+    float *swl = reinterpret_cast<float *>(smem + 16);
+    const int sw_bytes = ((radius + 1) * sw_len * 4 + 15) & ~15;
+    unsigned char *tile_raw = smem + 16 + sw_bytes;
+    if (threadIdx.x == 0)
+        *flag_word = 1;
+    __syncthreads();
+
+    const int tid = threadIdx.x;
+    const int img_idx = blockIdx.x / tiles_per_img;
+    const int t_in_img = blockIdx.x - img_idx * tiles_per_img;
+    const int tile_y0 = (t_in_img / tiles_x) * 64;
+    const int tile_x0 = (t_in_img % tiles_x) * kTileW;
+    const size_t img = (size_t)img_idx * h * w;
+    const int r4 = (radius + 3) & ~3;
+    const int tx = tid & 15;
+    const int ty = tid >> 4;
+
+    // ---- weight table, grey LUT (optimistic), grey-packed tile ----
+    for (int i = tid; i < (radius + 1) * sw_len; i += NT)
+        swl[i] = swsym[i];
+    float *lut_g = reinterpret_cast<float *>(smem + kT64Lds - nz * GREP * 4);
+    for (int i = tid; i < nz * GREP; i += NT)
+        lut_g[i] = lut[i / GREP];
+    uint32_t *tile4 = reinterpret_cast<uint32_t *>(tile_raw);
+    int grey = 1;
+    const int tlh = 64 + 2 * radius;
+    for (int ry = tid >> 6; ry < tlh; ry += NT >> 6) {
+        const int gy = border_interpolate(tile_y0 - radius + ry, h, border);
+        for (int X = tid & 63; X < TLW; X += 64) {
+            const int gx = border_interpolate(tile_x0 - r4 + X, w, border);
+            uint32_t t = 0u;
+            if (gy >= 0 && gx >= 0) {
+                const size_t q = img + (size_t)gy * w + gx;
+                const uint32_t sv = load_packed(src, q, SCN);
+                if (SCN == 3)
+                    grey &= (int)(((sv ^ (sv >> 8)) & 0xffffu) == 0u);
+                t = load_packed(joint, q, jcn) | (sv << 24);
+            }
+            tile4[ry * TLW + (X & 3) * Q4 + (X >> 2)] = t;
+        }
+    }
+    const int all_grey = block_all(grey, flag_word);  // also publishes sw table, LUT and tile
+    if (flags & 0x1000)  // benchmark aid: staging only (tools/jbf_tune.py --stage-only)
+        return;
+
+    const uint32_t sw_addr0 = lds_addr(swl);
+    if (SCN == 1 || all_grey) {
+        uint32_t jc[kPix];
+#pragma unroll
+        for (int p = 0; p < kPix; p++) {
+            const int X = 4 * tx + p + r4;
+            jc[p] = tile4[(ty + radius) * TLW + (X & 3) * Q4 + (X >> 2)] & 0x00ffffffu;
+        }
+        float sum1[kPix][1], wsum[kPix];
+#pragma unroll
+        for (int p = 0; p < kPix; p++) {
+            sum1[p][0] = 0.f;
+            wsum[p] = 0.f;
+        }
+        const uint32_t lut_lane_addr = lds_addr(lut_g) + (uint32_t)(tid & (GREP - 1)) * 4u;
+        const uint32_t tile_lane_addr = lds_addr(tile4) + (uint32_t)tx * 4u;
+        jbf_tap_loop<1, GREP, false, TLW, 4>(lut_lane_addr, sw_addr0, tile_lane_addr, jc, 0u, ty,
+                                             radius, r4, sw_len, hwtab, sum1, wsum);
+        const int oy = tile_y0 + ty;
+        if (oy < h) {
+#pragma unroll
+            for (int p = 0; p < kPix; p++) {
+                const int ox = tile_x0 + 4 * tx + p;
+                if (ox < w) {
+                    float s3[3] = {sum1[p][0], sum1[p][0], sum1[p][0]};
+                    finish_pixel(dst + (img + (size_t)oy * w + ox) * SCN, s3, wsum[p], SCN, flags);
+                }
+            }
+        }
+        return;
+    }
+
+    if constexpr (SCN == 3) {
+        // ---- colour src: two 32-row halves with 8-byte texels ----
+        uint2 *tile8 = reinterpret_cast<uint2 *>(tile_raw);
+        float *lut_c = reinterpret_cast<float *>(smem + kT64Lds - nz * CREP * 4);
+        const int tlh8 = 32 + 2 * radius;
+        for (int half = 0; half < 2; half++) {
+            const int y0 = tile_y0 + 32 * half;
+            if (y0 >= h)
+                break;
+            __syncthreads();  // everyone is done with the previous contents of the tile
+            if (half == 0)
+                for (int i = tid; i < nz * CREP; i += NT)
+                    lut_c[i] = lut[i / CREP];
+            for (int ry = tid >> 6; ry < tlh8; ry += NT >> 6) {
+                const int gy = border_interpolate(y0 - radius + ry, h, border);
+                for (int X = tid & 63; X < TLW; X += 64) {
+                    const int gx = border_interpolate(tile_x0 - r4 + X, w, border);
+                    uint2 t = make_uint2(0u, 0u);
+                    if (gy >= 0 && gx >= 0) {
+                        const size_t q = img + (size_t)gy * w + gx;
+                        t.x = load_packed(joint, q, jcn);
+                        t.y = load_packed(src, q, 3);
+                    }
+                    tile8[ry * TLW + (X & 3) * Q4 + (X >> 2)] = t;
+                }
+            }
+            __syncthreads();
+            if (tid < 512) {
+                uint32_t jc[kPix];
+#pragma unroll
+                for (int p = 0; p < kPix; p++) {
+                    const int X = 4 * tx + p + r4;
+                    jc[p] = tile8[(ty + radius) * TLW + (X & 3) * Q4 + (X >> 2)].x;
+                }
+                float sum[kPix][3], wsum[kPix];
+#pragma unroll
+                for (int p = 0; p < kPix; p++) {
+                    wsum[p] = 0.f;
+                    sum[p][0] = sum[p][1] = sum[p][2] = 0.f;
+                }
+                const uint32_t lut_lane_addr = lds_addr(lut_c) + (uint32_t)(tid & (CREP - 1)) * 4u;
+                const uint32_t tile_lane_addr = lds_addr(tile8) + (uint32_t)tx * 8u;
+                jbf_tap_loop<3, CREP, false, TLW, 8>(lut_lane_addr, sw_addr0, tile_lane_addr, jc,
+                                                     0u, ty, radius, r4, sw_len, hwtab, sum, wsum);
+                const int oy = y0 + ty;
+                if (oy < h) {
+#pragma unroll
+                    for (int p = 0; p < kPix; p++) {
+                        const int ox = tile_x0 + 4 * tx + p;
+                        if (ox < w)
+                            finish_pixel(dst + (img + (size_t)oy * w + ox) * 3, sum[p], wsum[p], 3,
+                                         flags);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Probe for the "LDS reads beyond the allocation return 0" behaviour the 64x64 kernel relies on.
+__global__ void lds_oob_probe_kernel(uint32_t *out)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t *w = reinterpret_cast<uint32_t *>(smem);
+    for (int i = threadIdx.x; i < kT64Lds / 4; i += blockDim.x)
+        w[i] = 0xdeadbeefu;
+    __syncthreads();
+    uint32_t bad = 0;
+    const uint32_t addrs[4] = {(uint32_t)kT64Lds + 4u * threadIdx.x, (uint32_t)kT64Lds + 61056u,
+                               262140u, (uint32_t)kT64Lds - 4u};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t v;
+        asm volatile("ds_read_b32 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addrs[k]));
+        bad |= (k < 3) ? (v != 0u) : (v != 0xdeadbeefu);
+    }
+    if (bad)
+        atomicOr(out, 1u);
+}
+
 struct Tiled2Config {
     int th, lutrep;
     bool full_lut;  // stage all 256*jcn LUT entries and skip the per-tap clamp
-    bool pairs;     // two columns per pipeline step
 };
 
 size_t tiled2_lds_bytes(const JbfTables &t, int th, int lutrep, bool full_lut)
@@ -747,10 +704,10 @@ size_t tiled2_lds_bytes(const JbfTables &t, int th, int lutrep, bool full_lut)
     const int lut_len = full_lut ? 256 * t.joint_cn : t.lut_len;
     const size_t lut_bytes = ((size_t)lut_len * lutrep * 4 + 15) & ~(size_t)15;
     const size_t sw_bytes = ((size_t)(t.radius + 1) * t.sw_len * 4 + 15) & ~(size_t)15;
-    return lut_bytes + sw_bytes + (size_t)kTlw2 * (th + 2 * t.radius) * sizeof(uint2);
+    return 16 + lut_bytes + sw_bytes + (size_t)kTlw2 * (th + 2 * t.radius) * sizeof(uint2);
 }
 
-template <int SCN, int TH, int LUTREP, bool PAIRS>
+template <int SCN, int TH, int LUTREP>
 int launch_tiled2(const JbfTables &t, bool full_lut, const uint8_t *joint, const uint8_t *src,
                   uint8_t *dst, int n, int h, int w, int jcn, int border, int flags,
                   hipStream_t stream)
@@ -762,8 +719,8 @@ int launch_tiled2(const JbfTables &t, bool full_lut, const uint8_t *joint, const
     const long long blocks = (long long)tiles_x * tiles_y * n;
     if (blocks > 0x7fffffffLL)
         return fail(RF_E_UNSUPPORTED, "rf_jbf_u8: batch too large for one launch");
-    auto kern = clamp ? jbf_tiled2_kernel<SCN, TH, LUTREP, true, PAIRS>
-                      : jbf_tiled2_kernel<SCN, TH, LUTREP, false, PAIRS>;
+    auto kern = clamp ? jbf_tiled2_kernel<SCN, TH, LUTREP, true>
+                      : jbf_tiled2_kernel<SCN, TH, LUTREP, false>;
     RF_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(16 * TH), lds, stream, joint, src, dst, h,
@@ -772,18 +729,61 @@ int launch_tiled2(const JbfTables &t, bool full_lut, const uint8_t *joint, const
     return RF_OK;
 }
 
-int tiled_geometry(int radius, int lut_len, int *tlw, int *tlh, size_t *lds_bytes)
+
+std::vector<int> g_oob_ok;  // per device: -1 unknown, 0 no, 1 yes (guarded by g_mu)
+
+// Runs the probe once per device.  Synchronises the device (only on the first JBF call).
+int lds_oob_reads_zero(int dev, bool *ok)
 {
-    int wv = kTileW + 2 * radius + (kPix - 1);
-    int tw = (wv + 31) / 32 * 32;  // multiple of 32 ...
-    if (tw - wv >= 16)
-        tw -= 16;  // ... or of 16 with tlw % 32 == 16
-    else
-        tw += 16;
-    *tlw = tw;
-    *tlh = kTileH + 2 * radius;
-    *lds_bytes = (size_t)lut_len * kLutRep * sizeof(float) + (size_t)tw * (*tlh) * sizeof(uint2);
-    return *lds_bytes <= (size_t)kMaxLds;
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        if ((int)g_oob_ok.size() <= dev)
+            g_oob_ok.resize(dev + 1, -1);
+        if (g_oob_ok[dev] >= 0) {
+            *ok = g_oob_ok[dev] == 1;
+            return RF_OK;
+        }
+    }
+    uint32_t *d_flag = nullptr;
+    RF_HIP_CHECK(hipMalloc(&d_flag, sizeof(uint32_t)));
+    RF_HIP_CHECK(hipMemset(d_flag, 0, sizeof(uint32_t)));
+    RF_HIP_CHECK(hipFuncSetAttribute((const void *)lds_oob_probe_kernel,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kT64Lds));
+    hipLaunchKernelGGL(lds_oob_probe_kernel, dim3(8), dim3(256), kT64Lds, 0, d_flag);
+    uint32_t flag = 1;
+    RF_HIP_CHECK(hipMemcpy(&flag, d_flag, sizeof(flag), hipMemcpyDeviceToHost));
+    (void)hipFree(d_flag);
+    std::lock_guard<std::mutex> lock(g_mu);
+    g_oob_ok[dev] = flag == 0 ? 1 : 0;
+    *ok = flag == 0;
+    return RF_OK;
+}
+
+// LDS needed by jbf_tile64_kernel for grey / colour tiles with the given LUT replication.
+bool tile64_fits(const JbfTables &t, int nz, int grep, int crep, int scn)
+{
+    const size_t sw_bytes = 16 + (((size_t)(t.radius + 1) * t.sw_len * 4 + 15) & ~(size_t)15);
+    const size_t grey = sw_bytes + (size_t)kTlw2 * (64 + 2 * t.radius) * 4 + (size_t)nz * grep * 4;
+    const size_t col = sw_bytes + (size_t)kTlw2 * (32 + 2 * t.radius) * 8 + (size_t)nz * crep * 4;
+    return grey <= (size_t)kT64Lds && (scn == 1 || col <= (size_t)kT64Lds);
+}
+
+template <int SCN, int GREP, int CREP>
+int launch_tile64(const JbfTables &t, int nz, const uint8_t *joint, const uint8_t *src,
+                  uint8_t *dst, int n, int h, int w, int jcn, int border, int flags,
+                  hipStream_t stream)
+{
+    const int tiles_x = ceil_div(w, kTileW), tiles_y = ceil_div(h, 64);
+    const long long blocks = (long long)tiles_x * tiles_y * n;
+    if (blocks > 0x7fffffffLL)
+        return fail(RF_E_UNSUPPORTED, "rf_jbf_u8: batch too large for one launch");
+    auto kern = jbf_tile64_kernel<SCN, GREP, CREP>;
+    RF_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     kT64Lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(1024), kT64Lds, stream, joint, src, dst,
+                       h, w, jcn, t.radius, border, t.d_lut, nz, t.d_hw, t.d_swsym, t.sw_len,
+                       tiles_x, tiles_x * tiles_y, flags);
+    return RF_OK;
 }
 
 }  // namespace
@@ -833,74 +833,70 @@ extern "C" int rf_jbf_u8(const uint8_t *joint, const uint8_t *src, uint8_t *dst,
         return rc;
 
     // ---- kernel selection -------------------------------------------------------------
-    // tune = 0: automatic.  1: first-generation tiled kernel.  2..12: v2 with a fixed
-    // (tile height, LUT replicas, full LUT, pair steps) configuration from kCfg.
+    // tune = 0: automatic; 1..6 force a (tile height, LUT replicas, full LUT) configuration of
+    // the tiled kernel (benchmark aid, tools/jbf_tune.py).
     const int tune = (flags >> RF_JBF_TUNE_SHIFT) & 0xf;
-    static const Tiled2Config kCfg[] = {
-        {32, 32, false, false}, {32, 16, false, false}, {48, 16, false, false},
-        {48, 8, false, false},  {32, 8, false, false},  {32, 8, true, false},
-        {48, 4, true, false},   {32, 8, true, true},    {48, 4, true, true},
-        {32, 32, false, true},  {48, 8, false, true}};
-    // measured on MI355X at 1080p (tools/jbf_tune.py): 3 waves/SIMD with a 16x replicated,
-    // clamped LUT wins for grey src; the clamp-free 8x table is next
-    static const int kAutoOrder[] = {2, 5, 0, 1, 4};
+    static const Tiled2Config kCfg[] = {{48, 16, false}, {32, 8, true},  {32, 32, false},
+                                        {32, 16, false}, {64, 16, false}, {48, 8, false}};
+    constexpr int kNumCfg = (int)(sizeof(kCfg) / sizeof(kCfg[0]));
+    // measured on MI355X at 1080p: 3 waves/SIMD with a 16x replicated, clamped LUT wins for grey
+    // src; the clamp-free 8x table is next
+    // tune 7 forces the 64x64 kernel, tune 1..6 the 64xTH kernel
+    bool done = false;
+    if (!(flags & RF_JBF_FORCE_GENERIC) && t.r4 <= 36 && (tune == 0 || tune == 7)) {
+        bool oob_ok = false;
+        rc = lds_oob_reads_zero(t.device, &oob_ok);
+        if (rc != RF_OK)
+            return rc;
+        // table entries before the zero tail (the whole table if it has none)
+        const int nz = t.lut_len < 256 * joint_cn ? t.lut_len - 1 : t.lut_len;
+        if (oob_ok) {
+#define RF_T64(G_, C_)                                                                         \
+    if (!done && tile64_fits(t, nz, G_, C_, src_cn)) {                                         \
+        rc = src_cn == 3 ? launch_tile64<3, G_, C_>(t, nz, joint, src, dst, n, h, w, joint_cn, \
+                                                    border, flags, stream)                     \
+                         : launch_tile64<1, G_, C_>(t, nz, joint, src, dst, n, h, w, joint_cn, \
+                                                    border, flags, stream);                    \
+        if (rc != RF_OK)                                                                       \
+            return rc;                                                                         \
+        done = true;                                                                           \
+    }
+            RF_T64(32, 16)
+            RF_T64(16, 8)
+            RF_T64(8, 4)
+#undef RF_T64
+        }
+    }
     int cfg = -1;
-    const bool v2_radius_ok = t.r4 <= 36;
-    if (!(flags & RF_JBF_FORCE_GENERIC) && v2_radius_ok) {
-        if (tune >= 2 && tune <= 12) {
-            const Tiled2Config &c = kCfg[tune - 2];
-            if (tiled2_lds_bytes(t, c.th, c.lutrep, c.full_lut) <= (size_t)kMaxLds)
-                cfg = tune - 2;
-        } else if (tune == 0) {
-            for (int ci : kAutoOrder) {
-                const Tiled2Config &c = kCfg[ci];
-                if (tiled2_lds_bytes(t, c.th, c.lutrep, c.full_lut) <= (size_t)kMaxLds) {
-                    cfg = ci;
-                    break;
-                }
+    if (!done && !(flags & RF_JBF_FORCE_GENERIC) && t.r4 <= 36 && tune != 7) {
+        for (int ci = 0; ci < kNumCfg; ci++) {
+            if (tune != 0 && tune != ci + 1)
+                continue;
+            const Tiled2Config &c = kCfg[ci];
+            if (tiled2_lds_bytes(t, c.th, c.lutrep, c.full_lut) <= (size_t)kMaxLds) {
+                cfg = ci;
+                break;
             }
         }
     }
-    int tlw = 0, tlh = 0;
-    size_t lds = 0;
-    const bool tiled_ok = tiled_geometry(radius, t.lut_len, &tlw, &tlh, &lds);
     if (cfg >= 0) {
-#define RF_T2_(TH_, REP_, P_)                                                                   \
-    rc = src_cn == 3                                                                            \
-             ? launch_tiled2<3, TH_, REP_, P_>(t, kCfg[cfg].full_lut, joint, src, dst, n, h, w,     \
-                                               joint_cn, border, flags, stream)                 \
-             : launch_tiled2<1, TH_, REP_, P_>(t, kCfg[cfg].full_lut, joint, src, dst, n, h, w,     \
-                                               joint_cn, border, flags, stream)
-#define RF_T2(TH_, REP_, P_) RF_T2_(TH_, REP_, P_)
+#define RF_T2(TH_, REP_)                                                                        \
+    rc = src_cn == 3 ? launch_tiled2<3, TH_, REP_>(t, kCfg[cfg].full_lut, joint, src, dst, n, h, \
+                                                   w, joint_cn, border, flags, stream)          \
+                     : launch_tiled2<1, TH_, REP_>(t, kCfg[cfg].full_lut, joint, src, dst, n, h, \
+                                                   w, joint_cn, border, flags, stream)
         switch (cfg) {
-        case 0: RF_T2(32, 32, false); break;
-        case 1: RF_T2(32, 16, false); break;
-        case 2: RF_T2(48, 16, false); break;
-        case 3: RF_T2(48, 8, false); break;
-        case 4: RF_T2(32, 8, false); break;
-        case 5: RF_T2(32, 8, false); break;
-        case 6: RF_T2(48, 4, false); break;
-        case 7: RF_T2(32, 8, true); break;
-        case 8: RF_T2(48, 4, true); break;
-        case 9: RF_T2(32, 32, true); break;
-        default: RF_T2(48, 8, true); break;
+        case 0: RF_T2(48, 16); break;
+        case 1: RF_T2(32, 8); break;
+        case 2: RF_T2(32, 32); break;
+        case 3: RF_T2(32, 16); break;
+        case 4: RF_T2(64, 16); break;
+        default: RF_T2(48, 8); break;
         }
-#undef RF_T2_
 #undef RF_T2
         if (rc != RF_OK)
             return rc;
-    } else if (tiled_ok && !(flags & RF_JBF_FORCE_GENERIC) && (tune == 0 || tune == 1)) {
-        const int tiles_x = ceil_div(w, kTileW), tiles_y = ceil_div(h, kTileH);
-        const long long blocks = (long long)tiles_x * tiles_y * n;
-        if (blocks > 0x7fffffffLL)
-            return fail(RF_E_UNSUPPORTED, "rf_jbf_u8: batch too large for one launch");
-        auto kern = src_cn == 3 ? jbf_tiled_kernel<3> : jbf_tiled_kernel<1>;
-        RF_HIP_CHECK(hipFuncSetAttribute((const void *)kern,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kThreads), lds, stream, joint, src,
-                           dst, h, w, joint_cn, radius, border, t.d_lut, t.lut_len, t.d_hw,
-                           t.d_swpad, t.sw_stride, tlw, tlh, tiles_x, tiles_x * tiles_y, flags);
-    } else {
+    } else if (!done) {
         dim3 grid(ceil_div(w, 64), ceil_div(h, 4), n);
         if (n > 65535)
             return fail(RF_E_UNSUPPORTED, "rf_jbf_u8: generic path supports n <= 65535");
