@@ -392,6 +392,159 @@ __device__ __forceinline__ void jbf_tap_loop(uint32_t lut_lane_addr, uint32_t sw
     }
 #undef RF_READ_TEXEL
 }
+
+// Hand-scheduled tap loop for grey tiles (4-byte texels, one accumulated channel), same
+// arithmetic and the same pipeline as jbf_tap_loop<1, LUTREP, false, TLW, 4>.
+//
+// Why asm: a gfx950 SIMD retires two wave-instructions per 4 cycles only if at most one of them
+// is a "full-pipe" opcode (v_sad_u8, v_lshl_add_u32, v_cvt_*, anything with an SGPR/constant
+// operand ...; 4 cycles each back to back) and the other a "simple" one (v_mul_f32 / v_add_f32 /
+// v_and_b32 on VGPRs; 2 cycles each) -- tools/microbench/valu_rates2.hip.  Per column this loop
+// needs 9 full-pipe and 17 simple instructions; hipcc emits them as an 8-instruction full-pipe
+// burst followed by the simple ones, the blocks below interleave them one for one.
+template <int LUTREP, int TLW>
+__device__ __forceinline__ void jbf_tap_loop_grey4(uint32_t lut_lane_addr, uint32_t sw_addr0,
+                                                   uint32_t tile_lane_addr,
+                                                   const uint32_t (&jc)[kPix], int ty, int radius,
+                                                   int r4, int sw_len,
+                                                   const int *__restrict__ hwtab,
+                                                   float (&sum)[kPix][1], float (&wsum)[kPix])
+{
+    constexpr int Q4 = TLW / 4;
+    constexpr int SHIFT = LUTREP == 32 ? 7 : LUTREP == 16 ? 6 : LUTREP == 8 ? 5 : 4;
+    static_assert(LUTREP == 32 || LUTREP == 16 || LUTREP == 8 || LUTREP == 4, "LUT replicas");
+    uint32_t mask = 0x00ffffffu;
+    asm volatile("" : "+v"(mask));  // keep the mask in a VGPR (a literal operand is full-pipe)
+
+    for (int i = -radius; i <= radius; i++) {
+        const int hw = hwtab[i + radius];
+        const int hw4 = (hw + 3) & ~3;
+        const int ai = i < 0 ? -i : i;
+        uint32_t ta = tile_lane_addr +
+                      (uint32_t)(((ty + i + radius) * TLW + ((r4 - hw4) >> 2)) * 4);
+        uint32_t wa_addr = sw_addr0 + (uint32_t)((ai * sw_len + (r4 + 8) + hw4 - 4) * 4);
+        const int ngroups = (hw4 >> 1) + 1;
+
+        uint32_t tq[4];
+        float4v wna, wnb;
+        float gg[2][kPix];
+        // prologue: texels of columns 0 and 1, weight window of group 0, gathers of column 0
+        asm volatile("ds_read_b32 %0, %2\n\t"
+                     "ds_read_b32 %1, %2 offset:%3"
+                     : "=&v"(tq[0]), "=&v"(tq[1])
+                     : "v"(ta), "n"(Q4 * 4));
+        asm volatile("ds_read_b128 %0, %2\n\t"
+                     "ds_read_b128 %1, %2 offset:16"
+                     : "=&v"(wna), "=&v"(wnb)
+                     : "v"(wa_addr));
+        asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(tq[0]));
+        {
+            const uint32_t tj = tq[0] & mask;
+#pragma unroll
+            for (int p = 0; p < kPix; p++) {
+                const uint32_t a =
+                    __builtin_amdgcn_sad_u8(tj, jc[p], 0u) * (LUTREP * 4u) + lut_lane_addr;
+                asm volatile("ds_read_b32 %0, %1" : "=v"(gg[0][p]) : "v"(a));
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(tq[1]), "+v"(wna), "+v"(wnb), "+v"(gg[0][0]), "+v"(gg[0][1]),
+                       "+v"(gg[0][2]), "+v"(gg[0][3]));
+
+#define RF_TEXEL_OFF4(U) (((((U) + 2) & 3) * Q4 + (((U) + 2) >> 2)) * 4)
+        // Column step U of a group: texel of column +2, SAD + gathers of column +1, accumulation
+        // of column +0.  GA = gathers being consumed, GB = gathers being issued (their registers
+        // first hold alpha, then the LDS address, then the LUT value).
+#define RF_G4_PART1(U, GA, GB)                                                                   \
+    float w0_, w1_, w2_, w3_, s_;                                                                \
+    uint32_t tj_;                                                                                \
+    asm volatile("ds_read_b32 %[tn], %[ta] offset:%[off]\n\t"                                    \
+                 "v_and_b32 %[tj], %[mask], %[t1]\n\t"                                           \
+                 "v_sad_u8 %[a0], %[tj], %[jc0], 0\n\t"                                          \
+                 "v_mul_f32 %[w0], %[wv0], %[g0]\n\t"                                            \
+                 "v_sad_u8 %[a1], %[tj], %[jc1], 0\n\t"                                          \
+                 "v_mul_f32 %[w1], %[wv1], %[g1]\n\t"                                            \
+                 "v_sad_u8 %[a2], %[tj], %[jc2], 0\n\t"                                          \
+                 "v_mul_f32 %[w2], %[wv2], %[g2]\n\t"                                            \
+                 "v_sad_u8 %[a3], %[tj], %[jc3], 0\n\t"                                          \
+                 "v_mul_f32 %[w3], %[wv3], %[g3]\n\t"                                            \
+                 "v_cvt_f32_ubyte3 %[s], %[t0]"                                                  \
+                 : [tn] "=&v"(tq[((U) + 2) & 3]), [tj] "=&v"(tj_), [a0] "=&v"(GB[0]),            \
+                   [a1] "=&v"(GB[1]), [a2] "=&v"(GB[2]), [a3] "=&v"(GB[3]), [w0] "=&v"(w0_),     \
+                   [w1] "=&v"(w1_), [w2] "=&v"(w2_), [w3] "=&v"(w3_), [s] "=&v"(s_)              \
+                 : [ta] "v"(ta), [off] "n"(RF_TEXEL_OFF4(U)), [mask] "v"(mask),                  \
+                   [t1] "v"(tq[((U) + 1) & 3]), [t0] "v"(tq[(U)]), [jc0] "v"(jc[0]),             \
+                   [jc1] "v"(jc[1]), [jc2] "v"(jc[2]), [jc3] "v"(jc[3]), [wv0] "v"(wv[4 - (U)]), \
+                   [wv1] "v"(wv[5 - (U)]), [wv2] "v"(wv[6 - (U)]), [wv3] "v"(wv[7 - (U)]),       \
+                   [g0] "v"(GA[0]), [g1] "v"(GA[1]), [g2] "v"(GA[2]), [g3] "v"(GA[3]));          \
+    asm volatile("v_lshl_add_u32 %[a0], %[a0], %[sh], %[la]\n\t"                                 \
+                 "v_add_f32 %[ws0], %[ws0], %[w0]\n\t"                                           \
+                 "ds_read_b32 %[a0], %[a0]\n\t"                                                  \
+                 "v_lshl_add_u32 %[a1], %[a1], %[sh], %[la]\n\t"                                 \
+                 "v_add_f32 %[ws1], %[ws1], %[w1]\n\t"                                           \
+                 "ds_read_b32 %[a1], %[a1]\n\t"                                                  \
+                 "v_lshl_add_u32 %[a2], %[a2], %[sh], %[la]\n\t"                                 \
+                 "v_add_f32 %[ws2], %[ws2], %[w2]\n\t"                                           \
+                 "ds_read_b32 %[a2], %[a2]\n\t"                                                  \
+                 "v_lshl_add_u32 %[a3], %[a3], %[sh], %[la]\n\t"                                 \
+                 "v_add_f32 %[ws3], %[ws3], %[w3]\n\t"                                           \
+                 "ds_read_b32 %[a3], %[a3]"                                                      \
+                 : [a0] "+v"(GB[0]), [a1] "+v"(GB[1]), [a2] "+v"(GB[2]), [a3] "+v"(GB[3]),       \
+                   [ws0] "+v"(wsum[0]), [ws1] "+v"(wsum[1]), [ws2] "+v"(wsum[2]),                \
+                   [ws3] "+v"(wsum[3])                                                           \
+                 : [sh] "n"(SHIFT), [la] "v"(lut_lane_addr), [w0] "v"(w0_), [w1] "v"(w1_),       \
+                   [w2] "v"(w2_), [w3] "v"(w3_));
+#define RF_G4_PART2(TN, GB, EXTRA_OPERANDS)                                                      \
+    asm volatile("v_mul_f32 %[w0], %[w0], %[s]\n\t"                                              \
+                 "v_mul_f32 %[w1], %[w1], %[s]\n\t"                                              \
+                 "v_mul_f32 %[w2], %[w2], %[s]\n\t"                                              \
+                 "v_mul_f32 %[w3], %[w3], %[s]\n\t"                                              \
+                 "v_add_f32 %[s0], %[s0], %[w0]\n\t"                                             \
+                 "v_add_f32 %[s1], %[s1], %[w1]\n\t"                                             \
+                 "v_add_f32 %[s2], %[s2], %[w2]\n\t"                                             \
+                 "v_add_f32 %[s3], %[s3], %[w3]\n\t"                                             \
+                 "s_waitcnt lgkmcnt(0)"                                                          \
+                 : [w0] "+v"(w0_), [w1] "+v"(w1_), [w2] "+v"(w2_), [w3] "+v"(w3_),               \
+                   [s0] "+v"(sum[0][0]), [s1] "+v"(sum[1][0]), [s2] "+v"(sum[2][0]),             \
+                   [s3] "+v"(sum[3][0]), "+v"(TN), "+v"(GB[0]), "+v"(GB[1]), "+v"(GB[2]),        \
+                   "+v"(GB[3]) EXTRA_OPERANDS                                                    \
+                 : [s] "v"(s_));
+
+        for (int gq = 0; gq < ngroups; gq++) {
+            float wv[8];
+            wv[0] = wna.x; wv[1] = wna.y; wv[2] = wna.z; wv[3] = wna.w;
+            wv[4] = wnb.x; wv[5] = wnb.y; wv[6] = wnb.z; wv[7] = wnb.w;
+            {
+                RF_G4_PART1(0, gg[0], gg[1])
+                RF_G4_PART2(tq[2], gg[1], )
+            }
+            {
+                RF_G4_PART1(1, gg[1], gg[0])
+                RF_G4_PART2(tq[3], gg[0], )
+            }
+            {
+                RF_G4_PART1(2, gg[0], gg[1])
+                RF_G4_PART2(tq[0], gg[1], )
+            }
+            {
+                RF_G4_PART1(3, gg[1], gg[0])
+                // the next group's weight window rides along with this step's reads
+                wa_addr -= 16;
+                asm volatile("ds_read_b128 %0, %2\n\t"
+                             "ds_read_b128 %1, %2 offset:16"
+                             : "=&v"(wna), "=&v"(wnb)
+                             : "v"(wa_addr));
+#define RF_COMMA_W , "+v"(wna), "+v"(wnb)
+                RF_G4_PART2(tq[1], gg[0], RF_COMMA_W)
+#undef RF_COMMA_W
+            }
+            ta += 4;
+        }
+#undef RF_G4_PART1
+#undef RF_G4_PART2
+#undef RF_TEXEL_OFF4
+    }
+}
 #undef RF_LDS_READ_B64
 #undef RF_LDS_READ_B128
 #undef RF_LDS_READ_B32
@@ -598,8 +751,12 @@ __global__ __launch_bounds__(1024) void jbf_tile64_kernel(
         }
         const uint32_t lut_lane_addr = lds_addr(lut_g) + (uint32_t)(tid & (GREP - 1)) * 4u;
         const uint32_t tile_lane_addr = lds_addr(tile4) + (uint32_t)tx * 4u;
-        jbf_tap_loop<1, GREP, false, TLW, 4>(lut_lane_addr, sw_addr0, tile_lane_addr, jc, 0u, ty,
-                                             radius, r4, sw_len, hwtab, sum1, wsum);
+        if (flags & 0x2000)  // benchmark aid: compiler-scheduled loop instead of the asm one
+            jbf_tap_loop<1, GREP, false, TLW, 4>(lut_lane_addr, sw_addr0, tile_lane_addr, jc, 0u,
+                                                 ty, radius, r4, sw_len, hwtab, sum1, wsum);
+        else
+            jbf_tap_loop_grey4<GREP, TLW>(lut_lane_addr, sw_addr0, tile_lane_addr, jc, ty, radius,
+                                          r4, sw_len, hwtab, sum1, wsum);
         const int oy = tile_y0 + ty;
         if (oy < h) {
 #pragma unroll

@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--grey", action="store_true", help="src = joint = grey map (BF(CNN,CNN))")
     ap.add_argument("--rgb-src", action="store_true", help="src = a second RGB scene")
     ap.add_argument("--stage-only", action="store_true", help="time tile staging alone")
+    ap.add_argument("--extra-flags", type=lambda v: int(v, 0), default=0,
+                    help="extra rf_jbf_u8 flag bits for the second pass over the variants")
     ap.add_argument("--libs", default="", help="comma-separated extra librf_hip builds to compare")
     args = ap.parse_args()
     import torch
@@ -51,8 +53,13 @@ def main():
     n, h, w, _ = src.shape
 
     def run(lib, tune, out):
+        extra = 0
+        if tune >= 100:  # variant + 100 = the same variant with --extra-flags set
+            tune -= 100
+            extra = args.extra_flags
         rc = lib.rf_jbf_u8(joint.data_ptr(), src.data_ptr(), out.data_ptr(), n, h, w, 3, 3, -1,
-                           args.sigma_color, args.sigma_spatial, 4, (tune << 8) | (0x1000 if args.stage_only else 0), stream)
+                           args.sigma_color, args.sigma_spatial, 4,
+                           (tune << 8) | extra | (0x1000 if args.stage_only else 0), stream)
         if rc != 0:
             raise RuntimeError("variant %d: %s" % (tune, lib.rf_last_error()))
 

@@ -24,6 +24,9 @@ constexpr int kIters = 4096 * 32;
 #define KERNEL(NAME, ASM)                                                                  \
     __global__ void NAME(unsigned *out, int iters, unsigned long long *clk)                \
     {                                                                                      \
+        extern __shared__ unsigned dyn_lds[];                                              \
+        if (iters < 0)                                                                     \
+            dyn_lds[threadIdx.x] = 1;                                                      \
         unsigned r0 = threadIdx.x * 2654435761u, r1 = r0 ^ 0x55, r2 = r0 + 77, r3 = r0 * 3, \
                  r4 = r0 + 5, r5 = r0 ^ 9, r6 = r0 + 11, r7 = r0 * 7;                       \
         const unsigned a = threadIdx.x | 0x01020304u, b = 0x3f800001u;                     \
@@ -102,13 +105,18 @@ void run(const char *name, kern_t k, int instr_per_op, unsigned *d_out, unsigned
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
-    for (int wps : {2, 4}) {
-        const int threads = 256 * wps > 1024 ? 1024 : 256 * wps;
-        const int blocks = 256 * ((256 * wps) / threads);
-        hipLaunchKernelGGL(k, dim3(blocks), dim3(threads), 0, 0, d_out, kIters / 4, nullptr);
+    for (int wps : {1, 2, 4, 8}) {
+        // 256-thread blocks (one wave per SIMD each); LDS per block caps blocks/CU = waves/SIMD;
+        // 16 rounds of blocks per CU so that placement imbalance averages out
+        const int threads = 256;
+        const int blocks = 256 * wps * 16;
+        const size_t lds = (160 * 1024) / wps - (wps > 1 ? 1024 : 0);
+        CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds));
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(threads), lds, 0, d_out, kIters / 64, nullptr);
         CHECK(hipDeviceSynchronize());
         CHECK(hipEventRecord(e0));
-        hipLaunchKernelGGL(k, dim3(blocks), dim3(threads), 0, 0, d_out, kIters, d_clk);
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(threads), lds, 0, d_out, kIters / 16, d_clk);
         CHECK(hipEventRecord(e1));
         CHECK(hipEventSynchronize(e1));
         float ms = 0;
@@ -116,10 +124,11 @@ void run(const char *name, kern_t k, int instr_per_op, unsigned *d_out, unsigned
         unsigned long long clk[2];
         CHECK(hipMemcpy(clk, d_clk, sizeof(clk), hipMemcpyDeviceToHost));
         const double ghz = (double)clk[0] / ((double)clk[1] * 10.0);  // realtime ticks are 100 MHz
-        const double winstr = (double)kIters * 16 * instr_per_op;       // per wave
-        const double cyc_per_instr_simd = (double)clk[0] / winstr / wps; // shader cycles per wave-instr per SIMD
-        printf("%-26s waves/SIMD=%d %8.3f ms  clock %.3f GHz  %.2f cycles/wave-instr/SIMD\n", name, wps,
-               ms, ghz, cyc_per_instr_simd);
+        const double winstr = (double)(kIters / 16) * 16 * instr_per_op;  // per wave
+        // every SIMD executes 16 rounds x wps waves
+        const double per_simd = winstr * 16.0 * wps;
+        printf("%-26s waves/SIMD=%d %8.3f ms  clock(blk0) %.3f GHz  %.2f cycles/wave-instr/SIMD (wall, at that clock)\n",
+               name, wps, ms, ghz, ms * 1e-3 * ghz * 1e9 / per_simd);
     }
 }
 
