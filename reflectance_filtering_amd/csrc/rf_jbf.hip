@@ -142,6 +142,65 @@ __device__ inline uint32_t load_packed(const uint8_t *img, size_t pix, int cn)
     return v;
 }
 
+// Four consecutive pixels (cn interleaved bytes each, any alignment) -> four packed dwords.
+__device__ inline void load_packed4(const uint8_t *img, size_t pix, int cn, uint32_t (&out)[4])
+{
+    const uint8_t *p = img + pix * cn;
+    if (cn == 3) {
+        uint32_t d0, d1, d2;  // one (unaligned) 12-byte load
+        __builtin_memcpy(&d0, p, 4);
+        __builtin_memcpy(&d1, p + 4, 4);
+        __builtin_memcpy(&d2, p + 8, 4);
+        out[0] = d0 & 0x00ffffffu;
+        out[1] = (d0 >> 24) | ((d1 & 0xffffu) << 8);
+        out[2] = (d1 >> 16) | ((d2 & 0xffu) << 16);
+        out[3] = d2 >> 8;
+    } else {
+        uint32_t d0;
+        __builtin_memcpy(&d0, p, 4);
+        out[0] = d0 & 0xffu;
+        out[1] = (d0 >> 8) & 0xffu;
+        out[2] = (d0 >> 16) & 0xffu;
+        out[3] = d0 >> 24;
+    }
+}
+
+// Packed joint/src values of the four tile columns X = 4k .. 4k+3 of one tile row (image row
+// gy >= 0 already border-interpolated, or gy < 0 = outside under BORDER_CONSTANT).  Interior
+// columns take the 12-byte path, columns that need border handling go pixel by pixel.
+__device__ inline void load_tile_quad(const uint8_t *joint, const uint8_t *src, size_t img, int gy,
+                                      int x_first, int w, int jcn, int scn, int border,
+                                      uint32_t (&jv)[4], uint32_t (&sv)[4])
+{
+    if (gy < 0) {
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            jv[u] = sv[u] = 0u;
+        return;
+    }
+    const size_t row = img + (size_t)gy * w;
+    if (x_first >= 0 && x_first + 3 < w) {
+        load_packed4(joint, row + x_first, jcn, jv);
+        load_packed4(src, row + x_first, scn, sv);
+        return;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int gx = border_interpolate(x_first + u, w, border);
+        jv[u] = gx < 0 ? 0u : load_packed(joint, row + gx, jcn);
+        sv[u] = gx < 0 ? 0u : load_packed(src, row + gx, scn);
+    }
+}
+
+// Workgroups are dealt round-robin to the 8 XCDs (blocks b and b+8 share an L2).  This maps the
+// launch index to a tile index such that every XCD works through one contiguous range of tiles,
+// so the halo a tile shares with its neighbours is served by that XCD's own L2.  Speed only.
+__device__ inline int xcd_contiguous_tile(int b, int nblocks)
+{
+    const int per = nblocks >> 3;
+    return b < (per << 3) ? (b & 7) * per + (b >> 3) : b;
+}
+
 __device__ inline void finish_pixel(uint8_t *o, const float *sum, float wsum, int scn, int flags)
 {
     if (flags & RF_JBF_TRUE_DIVISION) {
@@ -151,6 +210,48 @@ __device__ inline void finish_pixel(uint8_t *o, const float *sum, float wsum, in
         const float inv = __fdiv_rn(1.0f, wsum);
         for (int c = 0; c < scn; c++)
             o[c] = saturate_u8(__fmul_rn(sum[c], inv));
+    }
+}
+
+__device__ inline float finish_value(float sum, float wsum_or_inv, int flags)
+{
+    return (flags & RF_JBF_TRUE_DIVISION) ? __fdiv_rn(sum, wsum_or_inv) : __fmul_rn(sum, wsum_or_inv);
+}
+
+// Stores a lane's 4 horizontally adjacent outputs.  sums[p][c]; NCH_IN = 1 replicates the single
+// accumulated channel.  Interior quads of 3-channel images go out as one 12-byte store.
+template <int NCH_IN, int SCN>
+__device__ inline void store_quad(uint8_t *dst, size_t img, int oy, int ox0, int h, int w,
+                                  const float (&sum)[kPix][NCH_IN], const float (&wsum)[kPix],
+                                  int flags)
+{
+    if (oy >= h || ox0 >= w)
+        return;
+    uint8_t px[kPix][3];
+#pragma unroll
+    for (int p = 0; p < kPix; p++) {
+        const float d = (flags & RF_JBF_TRUE_DIVISION) ? wsum[p] : __fdiv_rn(1.0f, wsum[p]);
+#pragma unroll
+        for (int c = 0; c < SCN; c++)
+            px[p][c] = saturate_u8(finish_value(sum[p][NCH_IN == 1 ? 0 : c], d, flags));
+    }
+    uint8_t *o = dst + (img + (size_t)oy * w + ox0) * SCN;
+    if (SCN == 3 && ox0 + 3 < w) {
+        uint32_t d[3];
+        d[0] = px[0][0] | (px[0][1] << 8) | (px[0][2] << 16) | ((uint32_t)px[1][0] << 24);
+        d[1] = px[1][1] | (px[1][2] << 8) | (px[2][0] << 16) | ((uint32_t)px[2][1] << 24);
+        d[2] = px[2][2] | (px[3][0] << 8) | (px[3][1] << 16) | ((uint32_t)px[3][2] << 24);
+        __builtin_memcpy(o, d, 12);
+    } else if (SCN == 1 && ox0 + 3 < w) {
+        const uint32_t d = px[0][0] | (px[1][0] << 8) | (px[2][0] << 16) | ((uint32_t)px[3][0] << 24);
+        __builtin_memcpy(o, &d, 4);
+    } else {
+#pragma unroll
+        for (int p = 0; p < kPix; p++)
+            if (ox0 + p < w)
+#pragma unroll
+                for (int c = 0; c < SCN; c++)
+                    o[p * SCN + c] = px[p][c];
     }
 }
 
@@ -572,8 +673,9 @@ __global__ __launch_bounds__(16 * TH) void jbf_tiled2_kernel(
     __syncthreads();
 
     const int tid = threadIdx.x;
-    const int img_idx = blockIdx.x / tiles_per_img;
-    const int t_in_img = blockIdx.x - img_idx * tiles_per_img;
+    const int tile_id = xcd_contiguous_tile((int)blockIdx.x, (int)gridDim.x);
+    const int img_idx = tile_id / tiles_per_img;
+    const int t_in_img = tile_id - img_idx * tiles_per_img;
     const int tile_y0 = (t_in_img / tiles_x) * TH;
     const int tile_x0 = (t_in_img % tiles_x) * kTileW;
     const size_t img = (size_t)img_idx * h * w;
@@ -584,21 +686,17 @@ __global__ __launch_bounds__(16 * TH) void jbf_tiled2_kernel(
         lutrep[i] = lut[i / LUTREP];
     for (int i = tid; i < (radius + 1) * sw_len; i += NT)
         swl[i] = swsym[i];
-    const int tlw_used = TLW;  // includes the pipeline's look-ahead / zero-weight columns
     int grey = 1;  // every src texel staged by this thread has B == G == R
-    for (int ry = tid >> 6; ry < tlh; ry += NT >> 6) {
+    for (int item = tid; item < tlh * Q4; item += NT) {
+        const int ry = item / Q4, k = item - ry * Q4;
         const int gy = border_interpolate(tile_y0 - radius + ry, h, border);
-        for (int X = tid & 63; X < tlw_used; X += 64) {
-            const int gx = border_interpolate(tile_x0 - r4 + X, w, border);
-            uint2 t = make_uint2(0u, 0u);
-            if (gy >= 0 && gx >= 0) {
-                const size_t q = img + (size_t)gy * w + gx;
-                t.x = load_packed(joint, q, jcn);
-                t.y = load_packed(src, q, SCN);
-            }
+        uint32_t jv[4], sv[4];
+        load_tile_quad(joint, src, img, gy, tile_x0 - r4 + 4 * k, w, jcn, SCN, border, jv, sv);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
             if (SCN == 3)
-                grey &= (int)(((t.y ^ (t.y >> 8)) & 0xffffu) == 0u);
-            tile[ry * TLW + (X & 3) * Q4 + (X >> 2)] = t;
+                grey &= (int)(((sv[u] ^ (sv[u] >> 8)) & 0xffffu) == 0u);
+            tile[ry * TLW + u * Q4 + k] = make_uint2(jv[u], sv[u]);
         }
     }
     const int all_grey = block_all(grey, flag_word);  // also the barrier that publishes the tile
@@ -647,15 +745,7 @@ __global__ __launch_bounds__(16 * TH) void jbf_tiled2_kernel(
                 sum[p][c] = sum1[p][0];
     }
 
-    const int oy = tile_y0 + ty;
-    if (oy < h) {
-#pragma unroll
-        for (int p = 0; p < kPix; p++) {
-            const int ox = tile_x0 + 4 * tx + p;
-            if (ox < w)
-                finish_pixel(dst + (img + (size_t)oy * w + ox) * SCN, sum[p], wsum[p], SCN, flags);
-        }
-    }
+    store_quad<SCN, SCN>(dst, img, tile_y0 + ty, tile_x0 + 4 * tx, h, w, sum, wsum, flags);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -698,8 +788,9 @@ __global__ __launch_bounds__(1024) void jbf_tile64_kernel(
     __syncthreads();
 
     const int tid = threadIdx.x;
-    const int img_idx = blockIdx.x / tiles_per_img;
-    const int t_in_img = blockIdx.x - img_idx * tiles_per_img;
+    const int tile_id = xcd_contiguous_tile((int)blockIdx.x, (int)gridDim.x);
+    const int img_idx = tile_id / tiles_per_img;
+    const int t_in_img = tile_id - img_idx * tiles_per_img;
     const int tile_y0 = (t_in_img / tiles_x) * 64;
     const int tile_x0 = (t_in_img % tiles_x) * kTileW;
     const size_t img = (size_t)img_idx * h * w;
@@ -716,19 +807,17 @@ __global__ __launch_bounds__(1024) void jbf_tile64_kernel(
     uint32_t *tile4 = reinterpret_cast<uint32_t *>(tile_raw);
     int grey = 1;
     const int tlh = 64 + 2 * radius;
-    for (int ry = tid >> 6; ry < tlh; ry += NT >> 6) {
+    // one work item = 4 consecutive tile columns (4k..4k+3) of one tile row
+    for (int item = tid; item < tlh * Q4; item += NT) {
+        const int ry = item / Q4, k = item - ry * Q4;
         const int gy = border_interpolate(tile_y0 - radius + ry, h, border);
-        for (int X = tid & 63; X < TLW; X += 64) {
-            const int gx = border_interpolate(tile_x0 - r4 + X, w, border);
-            uint32_t t = 0u;
-            if (gy >= 0 && gx >= 0) {
-                const size_t q = img + (size_t)gy * w + gx;
-                const uint32_t sv = load_packed(src, q, SCN);
-                if (SCN == 3)
-                    grey &= (int)(((sv ^ (sv >> 8)) & 0xffffu) == 0u);
-                t = load_packed(joint, q, jcn) | (sv << 24);
-            }
-            tile4[ry * TLW + (X & 3) * Q4 + (X >> 2)] = t;
+        uint32_t jv[4], sv[4];
+        load_tile_quad(joint, src, img, gy, tile_x0 - r4 + 4 * k, w, jcn, SCN, border, jv, sv);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (SCN == 3)
+                grey &= (int)(((sv[u] ^ (sv[u] >> 8)) & 0xffffu) == 0u);
+            tile4[ry * TLW + u * Q4 + k] = jv[u] | (sv[u] << 24);
         }
     }
     const int all_grey = block_all(grey, flag_word);  // also publishes sw table, LUT and tile
@@ -757,17 +846,7 @@ __global__ __launch_bounds__(1024) void jbf_tile64_kernel(
         else
             jbf_tap_loop_grey4<GREP, TLW>(lut_lane_addr, sw_addr0, tile_lane_addr, jc, ty, radius,
                                           r4, sw_len, hwtab, sum1, wsum);
-        const int oy = tile_y0 + ty;
-        if (oy < h) {
-#pragma unroll
-            for (int p = 0; p < kPix; p++) {
-                const int ox = tile_x0 + 4 * tx + p;
-                if (ox < w) {
-                    float s3[3] = {sum1[p][0], sum1[p][0], sum1[p][0]};
-                    finish_pixel(dst + (img + (size_t)oy * w + ox) * SCN, s3, wsum[p], SCN, flags);
-                }
-            }
-        }
+        store_quad<1, SCN>(dst, img, tile_y0 + ty, tile_x0 + 4 * tx, h, w, sum1, wsum, flags);
         return;
     }
 
@@ -784,18 +863,14 @@ __global__ __launch_bounds__(1024) void jbf_tile64_kernel(
             if (half == 0)
                 for (int i = tid; i < nz * CREP; i += NT)
                     lut_c[i] = lut[i / CREP];
-            for (int ry = tid >> 6; ry < tlh8; ry += NT >> 6) {
+            for (int item = tid; item < tlh8 * Q4; item += NT) {
+                const int ry = item / Q4, k = item - ry * Q4;
                 const int gy = border_interpolate(y0 - radius + ry, h, border);
-                for (int X = tid & 63; X < TLW; X += 64) {
-                    const int gx = border_interpolate(tile_x0 - r4 + X, w, border);
-                    uint2 t = make_uint2(0u, 0u);
-                    if (gy >= 0 && gx >= 0) {
-                        const size_t q = img + (size_t)gy * w + gx;
-                        t.x = load_packed(joint, q, jcn);
-                        t.y = load_packed(src, q, 3);
-                    }
-                    tile8[ry * TLW + (X & 3) * Q4 + (X >> 2)] = t;
-                }
+                uint32_t jv[4], sv[4];
+                load_tile_quad(joint, src, img, gy, tile_x0 - r4 + 4 * k, w, jcn, 3, border, jv, sv);
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    tile8[ry * TLW + u * Q4 + k] = make_uint2(jv[u], sv[u]);
             }
             __syncthreads();
             if (tid < 512) {
@@ -815,16 +890,7 @@ __global__ __launch_bounds__(1024) void jbf_tile64_kernel(
                 const uint32_t tile_lane_addr = lds_addr(tile8) + (uint32_t)tx * 8u;
                 jbf_tap_loop<3, CREP, false, TLW, 8>(lut_lane_addr, sw_addr0, tile_lane_addr, jc,
                                                      0u, ty, radius, r4, sw_len, hwtab, sum, wsum);
-                const int oy = y0 + ty;
-                if (oy < h) {
-#pragma unroll
-                    for (int p = 0; p < kPix; p++) {
-                        const int ox = tile_x0 + 4 * tx + p;
-                        if (ox < w)
-                            finish_pixel(dst + (img + (size_t)oy * w + ox) * 3, sum[p], wsum[p], 3,
-                                         flags);
-                    }
-                }
+                store_quad<3, 3>(dst, img, y0 + ty, tile_x0 + 4 * tx, h, w, sum, wsum, flags);
             }
         }
     }

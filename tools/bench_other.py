@@ -1,0 +1,83 @@
+#!/usr/bin/env python
+"""Timing of the other two operators on the path (guided filter, CNN) and of the chained
+configurations of BASELINE.json (C3: CNN + BF(CNN,CNN) at IIW size; C5: 3x GF at 4K).
+
+    python tools/bench_other.py [--gf-batch 8] [--cnn-batch 256]
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def timed(torch, fn, reps=3):
+    fn()
+    torch.cuda.synchronize()
+    best = 1e30
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    return best
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gf-batch", type=int, default=8)
+    ap.add_argument("--cnn-batch", type=int, default=256)
+    args = ap.parse_args()
+    import torch
+    import bench
+    import reflectance_filtering_amd as rf
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    out = {}
+
+    # C5: 3x guided filter c=3 s=45 at 3840x2160, piecewise-constant guidance
+    n, h, w = args.gf_batch, 2160, 3840
+    scene, grey = bench.synth_batch(torch, n, h, w, 5000, dev)
+    flat = (scene // 32) * 32 + 16  # posterised scene = piecewise-constant "flat" guidance
+    dst = torch.empty_like(grey)
+    for iters in (1, 3):
+        ms = timed(torch, lambda: rf.ops.guided_filter_u8(flat, grey, 45, 3.0, iterations=iters,
+                                                          out=dst))
+        out["gf_4k_x%d" % iters] = {"ms": ms, "mp_per_s": n * h * w / 1e6 / (ms * 1e-3),
+                                    "batch": n}
+    del scene, grey, flat, dst
+    torch.cuda.empty_cache()
+
+    # C1-size guided filter, single image latency
+    scene, grey = bench.synth_batch(torch, 1, 256, 256, 5001, dev)
+    ms = timed(torch, lambda: rf.ops.guided_filter_u8(scene, grey, 52, 7.0))
+    out["gf_256_single"] = {"ms": ms}
+
+    # C3: CNN + BF(CNN,CNN) at 500x333
+    n, h, w = args.cnn_batch, 333, 500
+    scene, _ = bench.synth_batch(torch, n, h, w, 5002, dev)
+    ms_cnn = timed(torch, lambda: rf.get_reflectance_batch(scene))
+    out["cnn_iiw"] = {"ms": ms_cnn, "mp_per_s": n * h * w / 1e6 / (ms_cnn * 1e-3), "batch": n}
+    _, r8 = rf.get_reflectance_batch(scene)
+    r3 = r8.unsqueeze(-1).expand(-1, -1, -1, 3).contiguous()
+    r3b = r3.clone()
+    o = torch.empty_like(r3)
+    ms_bf = timed(torch, lambda: rf.ops.joint_bilateral_u8(r3b, r3, -1, 20, 22, out=o))
+    out["bf_cnn_cnn_iiw"] = {"ms": ms_bf, "mp_per_s": n * h * w / 1e6 / (ms_bf * 1e-3), "batch": n}
+
+    def chain():
+        _, q = rf.get_reflectance_batch(scene)
+        q3 = q.unsqueeze(-1).expand(-1, -1, -1, 3).contiguous()
+        rf.ops.joint_bilateral_u8(q3.clone(), q3, -1, 20, 22, out=o)
+    ms = timed(torch, chain)
+    out["c3_chain_iiw"] = {"ms": ms, "mp_per_s": n * h * w / 1e6 / (ms * 1e-3), "batch": n,
+                           "ms_per_image": ms / n}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

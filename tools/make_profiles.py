@@ -1,0 +1,128 @@
+#!/usr/bin/env python
+"""Condense the rocprofv3 outputs under gpurun_out/ into the committed summaries in profiles/.
+
+Expects the directories written by the measurement command recorded in profiles/README.md:
+prof_stats (--kernel-trace --stats), prof_fetch / prof_write (--pmc FETCH_SIZE / WRITE_SIZE on
+bench.py), prof_calib (--pmc FETCH_SIZE on tools/microbench/fetch_calib.bin), prof_sq / prof_grbm
+(SQ and GRBM counters on a 32-image launch) and bench_default.json.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "profiles")
+G = os.path.join(ROOT, "gpurun_out")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
+
+
+def newest(pattern):
+    files = sorted(glob.glob(os.path.join(G, pattern)), key=os.path.getmtime)
+    return files[-1] if files else None
+
+
+def counters(path, match):
+    per = collections.defaultdict(dict)
+    names = {}
+    for r in csv.DictReader(open(path)):
+        if match in r["Kernel_Name"]:
+            per[int(r["Dispatch_Id"])][r["Counter_Name"]] = float(r["Counter_Value"])
+            names[int(r["Dispatch_Id"])] = r["Kernel_Name"].split("(")[0]
+    return per, names
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    lines = []
+    # ---- kernel stats
+    stats = newest("prof_stats/*/*kernel_stats.csv")
+    rows = list(csv.DictReader(open(stats)))
+    with open(os.path.join(OUT, "%s_bench_kernel_stats.csv" % TAG), "w") as fh:
+        w = csv.writer(fh)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs",
+                    "MaxNs", "StdDev"])
+        for r in rows[:10]:
+            name = r["Name"] if len(r["Name"]) <= 140 else r["Name"][:137] + "..."
+            w.writerow([name, r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
+                        r["MinNs"], r["MaxNs"], r["StdDev"]])
+    jbf = [r for r in rows if "jbf" in r["Name"]][0]
+    avg_ms = float(jbf["AverageNs"]) / 1e6
+    # ---- bench line
+    bench = json.load(open(os.path.join(G, "bench_default.json")))
+    with open(os.path.join(OUT, "%s_bench.json" % TAG), "w") as fh:
+        json.dump(bench, fh, indent=1)
+    n, h, w_ = (bench["config"]["batch_per_gpu"], bench["config"]["height"],
+                bench["config"]["width"])
+    # ---- calibration of FETCH_SIZE
+    cal, names = counters(newest("prof_calib/*/*counter_collection.csv"), "read1")
+    calib = {}
+    for d, v in cal.items():
+        calib["read12" if "read12" in names[d] else "read16"] = v["FETCH_SIZE"] * 1024.0
+    true_bytes = float(3 << 30)
+    f12 = true_bytes / calib["read12"]
+    f16 = true_bytes / calib["read16"]
+    # ---- traffic of the bench launch
+    fe, _ = counters(newest("prof_fetch/*/*counter_collection.csv"), "jbf")
+    wr, _ = counters(newest("prof_write/*/*counter_collection.csv"), "jbf")
+    fetch_raw = sorted(v["FETCH_SIZE"] for v in fe.values())[len(fe) // 2] * 1024.0
+    write = sorted(v["WRITE_SIZE"] for v in wr.values())[len(wr) // 2] * 1024.0
+    fetch = fetch_raw * f12
+    traffic = {"batch": n, "height": h, "width": w_,
+               "fetch_size_raw_bytes": fetch_raw, "fetch_calibration_factor": f12,
+               "fetch_bytes": fetch, "write_bytes": write,
+               "hbm_bytes_per_launch": fetch + write,
+               "algorithmic_bytes_per_launch": 9.0 * n * h * w_,
+               "note": "FETCH_SIZE/WRITE_SIZE are in KiB; separate --pmc passes; FETCH_SIZE "
+                       "scaled by the factor measured with tools/microbench/fetch_calib.hip for "
+                       "12-byte-per-lane loads (16-byte-per-lane factor %.3f, cf. "
+                       "MI355X_MICROARCH.md HBM section)" % f16}
+    with open(os.path.join(OUT, "jbf_pmc_traffic.json"), "w") as fh:
+        json.dump(traffic, fh, indent=1)
+    # ---- SQ counters
+    sq, sqn = counters(newest("prof_sq/*/*counter_collection.csv"), "jbf")
+    gr, _ = counters(newest("prof_grbm/*/*counter_collection.csv"), "jbf")
+    first = min(sq)
+    c = sq[first]
+    gui = gr[min(gr)]["GRBM_GUI_ACTIVE"] / 8.0
+    simds, cus = 1024.0, 256.0
+    lines += [
+        "# %s — rocprofv3 summaries for bench.py (one MI355X)" % TAG, "",
+        "Kernel: `%s`, launch = %d x %dx%d images." % (jbf["Name"].split("(")[0], n, w_, h), "",
+        "| quantity | value |", "|---|---|",
+        "| bench.py value | %.0f MP/s (%.1f ms per 256-image step) |" % (bench["value"], bench["ms_per_step"]),
+        "| kernel average duration, `--kernel-trace --stats` (%s calls) | %.2f ms |" % (jbf["Calls"], avg_ms),
+        "| kernel duration from HIP events inside bench.py | %.2f ms |" % bench["roofline"]["kernel_ms"],
+        "| algorithmic bytes per launch (9 B/px) | %.3f GB |" % (traffic["algorithmic_bytes_per_launch"] / 1e9),
+        "| achieved on algorithmic bytes | %.1f GB/s = %.3f %% of 8 TB/s |" % (bench["roofline"]["achieved"], 100 * bench["roofline"]["frac"]),
+        "| WRITE_SIZE per launch | %.3f GB (= 3 B/px exactly) |" % (write / 1e9),
+        "| FETCH_SIZE per launch, raw | %.3f GB |" % (fetch_raw / 1e9),
+        "| FETCH_SIZE calibration (3 GiB read once): 12 B/lane loads | counter reads 1/%.3f of the bytes |" % f12,
+        "| FETCH_SIZE calibration: 16 B/lane loads | counter reads 1/%.3f of the bytes |" % f16,
+        "| HBM-side traffic per launch (calibrated fetch + write) | %.3f GB = %.2f x algorithmic |" % ((fetch + write) / 1e9, (fetch + write) / traffic["algorithmic_bytes_per_launch"]),
+        "| colour-src launch (secondary) | %.0f MP/s |" % bench.get("colour_src", {}).get("value", float("nan")),
+        "| CPU baseline (oracle, %d threads) | %.2f MP/s |" % (bench["cpu_baseline"]["cores"], bench["cpu_baseline"]["value"]),
+        "",
+        "SQ counters, 32-image launch of the same kernel (`%s`):" % sqn[first], "",
+        "| counter | value | reading |", "|---|---|---|",
+    ]
+    wave = c["SQ_WAVE_CYCLES"]
+    lines += [
+        "| GRBM_GUI_ACTIVE / 8 | %.3e cycles | kernel length in shader cycles |" % gui,
+        "| SQ_INSTS_VALU | %.3e | %.2f cycles per VALU wave-instruction per SIMD |" % (c["SQ_INSTS_VALU"], gui * simds / c["SQ_INSTS_VALU"]),
+        "| SQ_INSTS_LDS | %.3e | %.2f VALU per LDS instruction |" % (c["SQ_INSTS_LDS"], c["SQ_INSTS_VALU"] / c["SQ_INSTS_LDS"]),
+        "| SQ_LDS_IDX_ACTIVE | %.3e | LDS busy %.0f %% of the kernel |" % (c["SQ_LDS_IDX_ACTIVE"], 100 * c["SQ_LDS_IDX_ACTIVE"] / cus / gui),
+        "| SQ_LDS_BANK_CONFLICT | %.3e | %.2f %% of LDS-active cycles |" % (c["SQ_LDS_BANK_CONFLICT"], 100 * c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]),
+        "| SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES | %.0f %% | share of wave time issuing |" % (100 * c["SQ_ACTIVE_INST_ANY"] / wave),
+        "| SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES | %.0f %% | ready but not issued (pipe busy) |" % (100 * c["SQ_WAIT_INST_ANY"] / wave),
+        "| SQ_WAIT_ANY / SQ_WAVE_CYCLES | %.0f %% | parked in s_waitcnt / barrier |" % (100 * c["SQ_WAIT_ANY"] / wave),
+    ]
+    with open(os.path.join(OUT, "%s_jbf_pmc.md" % TAG), "w") as fh:
+        fh.write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
