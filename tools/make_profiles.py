@@ -24,13 +24,19 @@ def newest(pattern):
     return files[-1] if files else None
 
 
+def short_name(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    cut = name.find("(")
+    return name[:cut] if cut > 0 else name
+
+
 def counters(path, match):
     per = collections.defaultdict(dict)
     names = {}
     for r in csv.DictReader(open(path)):
         if match in r["Kernel_Name"]:
             per[int(r["Dispatch_Id"])][r["Counter_Name"]] = float(r["Counter_Value"])
-            names[int(r["Dispatch_Id"])] = r["Kernel_Name"].split("(")[0]
+            names[int(r["Dispatch_Id"])] = short_name(r["Kernel_Name"])
     return per, names
 
 
@@ -90,15 +96,15 @@ def main():
     simds, cus = 1024.0, 256.0
     lines += [
         "# %s — rocprofv3 summaries for bench.py (one MI355X)" % TAG, "",
-        "Kernel: `%s`, launch = %d x %dx%d images." % (jbf["Name"].split("(")[0], n, w_, h), "",
+        "Kernel: `%s`, launch = %d x %dx%d images." % (short_name(jbf["Name"]), n, w_, h), "",
         "| quantity | value |", "|---|---|",
         "| bench.py value | %.0f MP/s (%.1f ms per 256-image step) |" % (bench["value"], bench["ms_per_step"]),
         "| kernel average duration, `--kernel-trace --stats` (%s calls) | %.2f ms |" % (jbf["Calls"], avg_ms),
         "| kernel duration from HIP events inside bench.py | %.2f ms |" % bench["roofline"]["kernel_ms"],
         "| algorithmic bytes per launch (9 B/px) | %.3f GB |" % (traffic["algorithmic_bytes_per_launch"] / 1e9),
         "| achieved on algorithmic bytes | %.1f GB/s = %.3f %% of 8 TB/s |" % (bench["roofline"]["achieved"], 100 * bench["roofline"]["frac"]),
-        "| WRITE_SIZE per launch | %.3f GB (= 3 B/px exactly) |" % (write / 1e9),
-        "| FETCH_SIZE per launch, raw | %.3f GB |" % (fetch_raw / 1e9),
+        "| WRITE_SIZE per launch | %.3f GB (algorithmic 3 B/px = %.3f GB) |" % (write / 1e9, 3.0 * n * h * w_ / 1e9),
+        "| FETCH_SIZE per launch, raw | %.3f GB (x%.1f calibration = %.3f GB; algorithmic 6 B/px = %.3f GB) |" % (fetch_raw / 1e9, f12, fetch / 1e9, 6.0 * n * h * w_ / 1e9),
         "| FETCH_SIZE calibration (3 GiB read once): 12 B/lane loads | counter reads 1/%.3f of the bytes |" % f12,
         "| FETCH_SIZE calibration: 16 B/lane loads | counter reads 1/%.3f of the bytes |" % f16,
         "| HBM-side traffic per launch (calibrated fetch + write) | %.3f GB = %.2f x algorithmic |" % ((fetch + write) / 1e9, (fetch + write) / traffic["algorithmic_bytes_per_launch"]),
