@@ -4,6 +4,7 @@
 namespace rf {
 
 void jbf_shutdown();
+void cnn_shutdown();
 
 char *last_error_buf()
 {
@@ -29,5 +30,6 @@ extern "C" const char *rf_last_error(void) { return rf::last_error_buf(); }
 extern "C" int rf_shutdown(void)
 {
     rf::jbf_shutdown();
+    rf::cnn_shutdown();
     return RF_OK;
 }

@@ -1,4 +1,4 @@
-// rf_cnn.hip -- the shipped 1x1 reflectance CNN, one lane per pixel, for gfx950 (MI355X).
+// rf_cnn.hip -- the shipped 1x1 reflectance CNN for gfx950 (MI355X).
 //
 // Replaces caffe.Net.forward() on /root/reference/network_definition.prototxt:9-165 with
 // /root/reference/learned_weights.caffemodel, fed by imgCV2_to_caffeBlob
@@ -8,71 +8,184 @@
 //   h0 = relu(W0 x + b0); h_l = relu(W_l h_{l-1} + b_l), l=1..4      (32 channels each)
 //   z  = wf . [h0|h1|h2|h3|h4] + bf ;  r = 1/(1+exp(-z))
 // Each dot product is a float32 FMA chain over k ascending starting from 0, then + bias (the
-// bias is a second rank-1 gemm in Caffe).  No pass is a large dense contraction (K = 3/32/160
-// per pixel) and exact-f32 MFMA issues at the VALU rate on gfx950, so this is plain VALU code:
-// activations live in VGPRs, the 4,513 weights are wave-uniform scalar operands.
+// bias is a second rank-1 gemm in Caffe).
+//
+// Mapping: one lane = two pixels; the 32 activations of a pixel live in VGPRs; every FMA is a
+// v_pk_fma_f32 that advances TWO output channels of one pixel by one k, its weight pair
+// {W[o][k], W[o+1][k]} a wave-uniform 64-bit SGPR operand streamed with s_load_dwordx16 from a
+// pair-interleaved copy of the weights (cnn_pack_weights_kernel, 18 KB, rebuilt per call).  K is
+// 3/32/160 per pixel, so this is not a dense contraction worth MFMA tiles; packed FMAs double
+// the plain v_fma_f32 rate, which on gfx950 issues on the 4-cycle "full" pipe
+// (tools/microbench/valu_rates2.hip).  The channel-pair loop is kept rolled: fully unrolled,
+// hipcc hoists all 4,513 weights into SGPRs at once and spills them to VGPR lanes.
+#include <mutex>
+#include <vector>
+
 #include "rf_common.hpp"
 
 namespace rf {
 namespace {
 
-__global__ __launch_bounds__(256) void cnn_reflectance_kernel(
-    const uint8_t *__restrict__ bgr, float *__restrict__ r_out, uint8_t *__restrict__ r_u8_out,
-    size_t npix, const float *__restrict__ wts, const float *__restrict__ srgb_lut)
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+constexpr int kPxPerLane = 2;
+constexpr int kPackedFloats = 2 * 16 * 3 + 32 + 4 * (2 * 16 * 32 + 32) + 160 + 1;
+// packed layout (floats):
+//   [0, 96)          layer 0 pairs: for op in 0..15, k in 0..2: {W0[2op][k], W0[2op+1][k]}
+//   [96, 128)        b0
+//   then 4 x { 1024 floats: for op in 0..15, k in 0..31: {W[2op][k], W[2op+1][k]} ; 32 bias }
+//   then wf[160], bf
+
+__global__ void cnn_pack_weights_kernel(const float *__restrict__ w, float *__restrict__ packed)
 {
-    __shared__ float lut[256];
-    lut[threadIdx.x] = srgb_lut[threadIdx.x];
-    __syncthreads();
-    const float *W0 = wts, *b0 = wts + 96;
-    const float *wf = wts + 128 + 4 * 1056, *bf = wf + 160;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix;
-         i += (size_t)gridDim.x * 256) {
-        const uint8_t *px = bgr + i * 3;
-        const float x0 = lut[px[2]], x1 = lut[px[1]], x2 = lut[px[0]];  // blob order is RGB
-        float cur[32], nxt[32];
-        float z = 0.f;
-#pragma unroll
-        for (int o = 0; o < 32; o++) {
-            float acc = __fmaf_rn(W0[o * 3 + 0], x0, 0.f);
-            acc = __fmaf_rn(W0[o * 3 + 1], x1, acc);
-            acc = __fmaf_rn(W0[o * 3 + 2], x2, acc);
-            acc = __fadd_rn(acc, b0[o]);
-            cur[o] = fmaxf(acc, 0.f);
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < 96) {  // layer 0
+        const int op = t / 6, rem = t % 6, k = rem / 2, half = rem % 2;
+        packed[t] = w[(2 * op + half) * 3 + k];
+    } else if (t < 128) {
+        packed[t] = w[t];
+    } else if (t < 128 + 4 * 1056) {
+        const int l = (t - 128) / 1056, q = (t - 128) % 1056;
+        const float *wl = w + 128 + l * 1056;
+        if (q < 1024) {
+            const int op = q / 64, rem = q % 64, k = rem / 2, half = rem % 2;
+            packed[t] = wl[(2 * op + half) * 32 + k];
+        } else {
+            packed[t] = wl[q];
         }
-#pragma unroll
-        for (int k = 0; k < 32; k++)
-            z = __fmaf_rn(wf[k], cur[k], z);
-#pragma unroll
-        for (int l = 0; l < 4; l++) {
-            const float *W = wts + 128 + l * 1056;
-            const float *b = W + 1024;
-#pragma unroll
-            for (int o = 0; o < 32; o++) {
-                float acc = 0.f;
-#pragma unroll
-                for (int k = 0; k < 32; k++)
-                    acc = __fmaf_rn(W[o * 32 + k], cur[k], acc);
-                acc = __fadd_rn(acc, b[o]);
-                nxt[o] = fmaxf(acc, 0.f);
-            }
-#pragma unroll
-            for (int k = 0; k < 32; k++) {
-                cur[k] = nxt[k];
-                z = __fmaf_rn(wf[32 * (l + 1) + k], cur[k], z);
-            }
-        }
-        z = __fadd_rn(z, bf[0]);
-        // caffe: 1. / (1. + exp(-x)) with a float exp; expf modelled as round(exp in double)
-        const float e = (float)exp((double)(-z));
-        const float r = (float)(1.0 / (1.0 + (double)e));
-        if (r_out)
-            r_out[i] = r;
-        if (r_u8_out)
-            r_u8_out[i] = (uint8_t)__fmul_rn(r, 255.0f);  // astype(uint8): truncation
+    } else if (t < RF_CNN_NPARAMS) {
+        packed[t] = w[t];
     }
 }
 
+constexpr int kCnnThreads = 128;
+
+__device__ __forceinline__ float2v splat(float v) { return float2v{v, v}; }
+
+// One layer for the lane's two pixels: 16 channel pairs x K steps of v_pk_fma_f32.  The channel
+// pair loop is a real loop (so only one pair's 64 weights are live in SGPRs at a time); its
+// results go through a lane-private column of LDS because registers cannot be indexed by the
+// loop counter: act[ch][lane] holds {pixel 0, pixel 1}.
+template <int K>
+__device__ __forceinline__ void layer_pairs(const float *__restrict__ wp,
+                                            const float *__restrict__ bias,
+                                            const float (&in)[kPxPerLane][K == 3 ? 3 : 32],
+                                            float2v (*act)[kCnnThreads])
+{
+    const int lane = threadIdx.x;
+#pragma unroll 1
+    for (int op = 0; op < 16; op++) {
+        const float2v *wq = reinterpret_cast<const float2v *>(wp) + op * K;
+        float2v acc[kPxPerLane];
+#pragma unroll
+        for (int p = 0; p < kPxPerLane; p++)
+            acc[p] = float2v{0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const float2v w2 = wq[k];
+#pragma unroll
+            for (int p = 0; p < kPxPerLane; p++)
+                acc[p] = __builtin_elementwise_fma(w2, splat(in[p][k]), acc[p]);
+        }
+        const float b0 = bias[2 * op], b1 = bias[2 * op + 1];
+        act[2 * op][lane] = float2v{fmaxf(__fadd_rn(acc[0].x, b0), 0.f),
+                                    fmaxf(__fadd_rn(acc[1].x, b0), 0.f)};
+        act[2 * op + 1][lane] = float2v{fmaxf(__fadd_rn(acc[0].y, b1), 0.f),
+                                        fmaxf(__fadd_rn(acc[1].y, b1), 0.f)};
+    }
+}
+
+// Reads the layer's activations back into registers and adds its 32 terms of the fuse dot product
+__device__ __forceinline__ void collect(float2v (*act)[kCnnThreads], const float *__restrict__ wf32,
+                                        float (&cur)[kPxPerLane][32], float (&z)[kPxPerLane])
+{
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+        const float2v v = act[k][lane];
+        cur[0][k] = v.x;
+        cur[1][k] = v.y;
+        z[0] = __fmaf_rn(wf32[k], v.x, z[0]);
+        z[1] = __fmaf_rn(wf32[k], v.y, z[1]);
+    }
+}
+
+__global__ __launch_bounds__(kCnnThreads) void cnn_reflectance_kernel(
+    const uint8_t *__restrict__ bgr, float *__restrict__ r_out, uint8_t *__restrict__ r_u8_out,
+    size_t npix, const float *__restrict__ packed, const float *__restrict__ srgb_lut)
+{
+    __shared__ float lut[256];
+    __shared__ float2v act[32][kCnnThreads];
+    for (int i = threadIdx.x; i < 256; i += kCnnThreads)
+        lut[i] = srgb_lut[i];
+    __syncthreads();
+    const float *wf = packed + 128 + 4 * 1056;
+    const size_t stride = (size_t)gridDim.x * kCnnThreads;
+    // lane handles pixels i and i + half (both halves stay coalesced)
+    const size_t half = (npix + 1) / 2;
+    for (size_t i = (size_t)blockIdx.x * kCnnThreads + threadIdx.x; i < half; i += stride) {
+        size_t idx[kPxPerLane] = {i, i + half};
+        float x[kPxPerLane][3];
+#pragma unroll
+        for (int p = 0; p < kPxPerLane; p++) {
+            const size_t q = idx[p] < npix ? idx[p] : npix - 1;
+            const uint8_t *px = bgr + q * 3;
+            x[p][0] = lut[px[2]];  // blob channel order is RGB
+            x[p][1] = lut[px[1]];
+            x[p][2] = lut[px[0]];
+        }
+        float cur[kPxPerLane][32];
+        float z[kPxPerLane] = {0.f, 0.f};
+        layer_pairs<3>(packed, packed + 96, x, act);
+        collect(act, wf, cur, z);
+#pragma unroll 1
+        for (int l = 0; l < 4; l++) {
+            const float *wl = packed + 128 + l * 1056;
+            layer_pairs<32>(wl, wl + 1024, cur, act);
+            collect(act, wf + 32 * (l + 1), cur, z);
+        }
+#pragma unroll
+        for (int p = 0; p < kPxPerLane; p++) {
+            if (idx[p] >= npix)
+                continue;
+            const float zz = __fadd_rn(z[p], wf[160]);
+            // caffe: 1. / (1. + exp(-x)) with a float exp; expf modelled as round(exp in double)
+            const float e = (float)exp((double)(-zz));
+            const float r = (float)(1.0 / (1.0 + (double)e));
+            if (r_out)
+                r_out[idx[p]] = r;
+            if (r_u8_out)
+                r_u8_out[idx[p]] = (uint8_t)__fmul_rn(r, 255.0f);  // astype(uint8): truncation
+        }
+    }
+}
+
+std::mutex g_cnn_mu;
+std::vector<float *> g_packed;  // per device
+
+int packed_buffer(float **out)
+{
+    int dev = 0;
+    RF_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_cnn_mu);
+    if ((int)g_packed.size() <= dev)
+        g_packed.resize(dev + 1, nullptr);
+    if (!g_packed[dev])
+        RF_HIP_CHECK(hipMalloc(&g_packed[dev], sizeof(float) * kPackedFloats));
+    *out = g_packed[dev];
+    return RF_OK;
+}
+
 }  // namespace
+
+void cnn_shutdown()
+{
+    std::lock_guard<std::mutex> lock(g_cnn_mu);
+    for (float *p : g_packed)
+        (void)hipFree(p);
+    g_packed.clear();
+}
+
 }  // namespace rf
 
 extern "C" int rf_cnn_reflectance_u8(const uint8_t *bgr, float *r_out, uint8_t *r_u8_out, int n,
@@ -80,18 +193,29 @@ extern "C" int rf_cnn_reflectance_u8(const uint8_t *bgr, float *r_out, uint8_t *
                                      void *stream_)
 {
     using namespace rf;
+    static_assert(kPackedFloats == RF_CNN_NPARAMS, "packed layout is a permutation");
     if (!bgr || !weights || !srgb_lut || (!r_out && !r_u8_out))
         return fail(RF_E_BADARG, "rf_cnn_reflectance_u8: NULL pointer");
     if (n < 0 || h <= 0 || w <= 0)
         return fail(RF_E_BADARG, "rf_cnn_reflectance_u8: bad size n=%d h=%d w=%d", n, h, w);
     if (n == 0)
         return RF_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    float *packed = nullptr;
+    int rc = packed_buffer(&packed);
+    if (rc != RF_OK)
+        return rc;
+    // (the packed copy is rebuilt on the caller's stream every call: the weights may have changed,
+    //  and calls on one stream are ordered; concurrent calls on different streams of one device
+    //  must use the same weights)
+    hipLaunchKernelGGL(cnn_pack_weights_kernel, dim3((RF_CNN_NPARAMS + 255) / 256), dim3(256), 0,
+                       stream, weights, packed);
     const size_t npix = (size_t)n * h * w;
-    size_t blocks = (npix + 255) / 256;
-    if (blocks > 256 * 32)
-        blocks = 256 * 32;
-    hipLaunchKernelGGL(cnn_reflectance_kernel, dim3((unsigned)blocks), dim3(256), 0,
-                       (hipStream_t)stream_, bgr, r_out, r_u8_out, npix, weights, srgb_lut);
+    size_t blocks = ((npix + 1) / 2 + kCnnThreads - 1) / kCnnThreads;
+    if (blocks > 256 * 20)
+        blocks = 256 * 20;
+    hipLaunchKernelGGL(cnn_reflectance_kernel, dim3((unsigned)blocks), dim3(kCnnThreads), 0, stream,
+                       bgr, r_out, r_u8_out, npix, packed, srgb_lut);
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;
 }
