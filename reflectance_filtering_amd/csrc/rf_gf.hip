@@ -56,6 +56,20 @@ struct Quant {
     }
 };
 
+// Inclusive prefix sum over the 64 lanes of a wave with DPP moves (4 shifts inside each row of
+// 16 lanes, then the row totals are broadcast forward): 6 VALU instructions instead of the 6
+// ds_bpermute round trips of a __shfl_up scan.
+__device__ inline uint32_t wave_inclusive_scan(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);  // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); // row_bcast:15
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); // row_bcast:31
+    return v;
+}
+
 __device__ inline float mean_of(uint32_t s, double scale) { return (float)((double)s * scale); }
 
 // index into the 6-entry symmetric store: (0,0)=0 (0,1)=1 (0,2)=2 (1,1)=3 (1,2)=4 (2,2)=5
@@ -125,13 +139,7 @@ __global__ __launch_bounds__(kAThreads) void gf_stage1_kernel(
         uint32_t incl[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
-            uint32_t s = V[0][q] + V[1][q];
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t nb = __shfl_up(s, off);
-                if (lane >= off)
-                    s += nb;
-            }
+            const uint32_t s = wave_inclusive_scan(V[0][q] + V[1][q]);
             incl[q] = s;
             if (lane == 63)
                 wave_tot[q][wave] = s;
