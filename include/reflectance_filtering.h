@@ -43,6 +43,9 @@ extern "C" {
 /* rf_jbf_u8 flags */
 #define RF_JBF_TRUE_DIVISION 1 /* dst = sum / wsum; default is OpenCV's sum * (1.f / wsum) */
 #define RF_JBF_FORCE_GENERIC 2 /* use the untiled global-memory kernel (debug / cross-check) */
+#define RF_JBF_GREY_AS_BGR 4    /* a 1-channel joint counts as 3 equal channels, i.e. what cv2.imread makes of a
+                                 grey PNG (colour distance 3*|d|); with a 1-channel src the 1-channel result
+                                 equals every channel of the 3-channel one */
 #define RF_JBF_TUNE_SHIFT 8    /* bits 8..11: kernel-variant override used by the benchmarks; 0 = auto */
 
 int rf_version(void);

@@ -17,6 +17,7 @@ BORDER_CONSTANT, BORDER_REPLICATE, BORDER_REFLECT, BORDER_WRAP, BORDER_REFLECT_1
 BORDER_DEFAULT = BORDER_REFLECT_101
 JBF_TRUE_DIVISION = 1
 JBF_FORCE_GENERIC = 2
+JBF_GREY_AS_BGR = 4
 CNN_NPARAMS = 4513
 
 EXPORTS = ("rf_version", "rf_last_error", "rf_shutdown", "rf_jbf_u8", "rf_gf_workspace_bytes",

@@ -133,8 +133,11 @@ int get_tables(int radius, int joint_cn, double sigma_color, double sigma_space,
 
 // Packs up to 3 interleaved bytes into the low bytes of a dword (byte 3 = 0), so that
 // v_sad_u8 on two such dwords is the L1 colour distance.
+// cn = -1: single-channel image treated as three equal channels (RF_JBF_GREY_AS_BGR).
 __device__ inline uint32_t load_packed(const uint8_t *img, size_t pix, int cn)
 {
+    if (cn < 0)
+        return (uint32_t)img[pix] * 0x010101u;
     const uint8_t *p = img + pix * cn;
     uint32_t v = p[0];
     if (cn == 3)
@@ -145,7 +148,7 @@ __device__ inline uint32_t load_packed(const uint8_t *img, size_t pix, int cn)
 // Four consecutive pixels (cn interleaved bytes each, any alignment) -> four packed dwords.
 __device__ inline void load_packed4(const uint8_t *img, size_t pix, int cn, uint32_t (&out)[4])
 {
-    const uint8_t *p = img + pix * cn;
+    const uint8_t *p = img + pix * (cn < 0 ? 1 : cn);
     if (cn == 3) {
         uint32_t d0, d1, d2;  // one (unaligned) 12-byte load
         __builtin_memcpy(&d0, p, 4);
@@ -158,10 +161,11 @@ __device__ inline void load_packed4(const uint8_t *img, size_t pix, int cn, uint
     } else {
         uint32_t d0;
         __builtin_memcpy(&d0, p, 4);
-        out[0] = d0 & 0xffu;
-        out[1] = (d0 >> 8) & 0xffu;
-        out[2] = (d0 >> 16) & 0xffu;
-        out[3] = d0 >> 24;
+        const uint32_t rep = cn < 0 ? 0x010101u : 1u;
+        out[0] = (d0 & 0xffu) * rep;
+        out[1] = ((d0 >> 8) & 0xffu) * rep;
+        out[2] = ((d0 >> 16) & 0xffu) * rep;
+        out[3] = (d0 >> 24) * rep;
     }
 }
 
@@ -935,8 +939,8 @@ int launch_tiled2(const JbfTables &t, bool full_lut, const uint8_t *joint, const
                   uint8_t *dst, int n, int h, int w, int jcn, int border, int flags,
                   hipStream_t stream)
 {
-    const int lut_len = full_lut ? 256 * jcn : t.lut_len;
-    const bool clamp = lut_len < 256 * jcn;
+    const int lut_len = full_lut ? 256 * t.joint_cn : t.lut_len;
+    const bool clamp = lut_len < 256 * t.joint_cn;
     const size_t lds = tiled2_lds_bytes(t, TH, LUTREP, full_lut);
     const int tiles_x = ceil_div(w, kTileW), tiles_y = ceil_div(h, TH);
     const long long blocks = (long long)tiles_x * tiles_y * n;
@@ -1050,6 +1054,12 @@ extern "C" int rf_jbf_u8(const uint8_t *joint, const uint8_t *src, uint8_t *dst,
     if (radius > 4096)
         return fail(RF_E_UNSUPPORTED, "rf_jbf_u8: radius %d too large", radius);
     hipStream_t stream = (hipStream_t)stream_;
+    // RF_JBF_GREY_AS_BGR: a 1-channel joint counts as 3 equal channels (colour distance 3*|d|,
+    // 766-entry LUT); the kernels get joint_cn = -1 and replicate the byte while staging
+    const int joint_cn_arg = joint_cn;
+    if ((flags & RF_JBF_GREY_AS_BGR) && joint_cn == 1)
+        joint_cn = 3;
+    const int jcn_kernel = joint_cn_arg == 1 && joint_cn == 3 ? -1 : joint_cn;
     JbfTables t;
     int rc = get_tables(radius, joint_cn, sigma_color, sigma_space, &t);
     if (rc != RF_OK)
@@ -1076,9 +1086,9 @@ extern "C" int rf_jbf_u8(const uint8_t *joint, const uint8_t *src, uint8_t *dst,
         if (oob_ok) {
 #define RF_T64(G_, C_)                                                                         \
     if (!done && tile64_fits(t, nz, G_, C_, src_cn)) {                                         \
-        rc = src_cn == 3 ? launch_tile64<3, G_, C_>(t, nz, joint, src, dst, n, h, w, joint_cn, \
+        rc = src_cn == 3 ? launch_tile64<3, G_, C_>(t, nz, joint, src, dst, n, h, w, jcn_kernel, \
                                                     border, flags, stream)                     \
-                         : launch_tile64<1, G_, C_>(t, nz, joint, src, dst, n, h, w, joint_cn, \
+                         : launch_tile64<1, G_, C_>(t, nz, joint, src, dst, n, h, w, jcn_kernel, \
                                                     border, flags, stream);                    \
         if (rc != RF_OK)                                                                       \
             return rc;                                                                         \
@@ -1105,9 +1115,9 @@ extern "C" int rf_jbf_u8(const uint8_t *joint, const uint8_t *src, uint8_t *dst,
     if (cfg >= 0) {
 #define RF_T2(TH_, REP_)                                                                        \
     rc = src_cn == 3 ? launch_tiled2<3, TH_, REP_>(t, kCfg[cfg].full_lut, joint, src, dst, n, h, \
-                                                   w, joint_cn, border, flags, stream)          \
+                                                   w, jcn_kernel, border, flags, stream)        \
                      : launch_tiled2<1, TH_, REP_>(t, kCfg[cfg].full_lut, joint, src, dst, n, h, \
-                                                   w, joint_cn, border, flags, stream)
+                                                   w, jcn_kernel, border, flags, stream)
         switch (cfg) {
         case 0: RF_T2(48, 16); break;
         case 1: RF_T2(32, 8); break;
@@ -1124,7 +1134,7 @@ extern "C" int rf_jbf_u8(const uint8_t *joint, const uint8_t *src, uint8_t *dst,
         if (n > 65535)
             return fail(RF_E_UNSUPPORTED, "rf_jbf_u8: generic path supports n <= 65535");
         hipLaunchKernelGGL(jbf_generic_kernel, grid, dim3(256), 0, stream, joint, src, dst, h, w,
-                           joint_cn, src_cn, border, t.d_lut, t.d_di, t.d_dj, t.d_sw, t.maxk,
+                           jcn_kernel, src_cn, border, t.d_lut, t.d_di, t.d_dj, t.d_sw, t.maxk,
                            flags);
     }
     RF_HIP_CHECK(hipGetLastError());

@@ -98,6 +98,17 @@ def get_reflectance_batch(images, weights=None):
     return ops.cnn_reflectance_u8(images, weights=weights)
 
 
+def decompose_and_filter_batch(images, sigma_color=20.0, sigma_spatial=22.0, weights=None):
+    """BF(CNN, CNN) on the device, the paper's headline pipeline (README.md:56 of the reference):
+    CUDA uint8 BGR [N,H,W,3] -> (r_u8 [N,H,W], filtered [N,H,W]) with `filtered` bit-identical to
+    what the two CLIs produce through `<base>-r.png` (grey PNG re-read as 3 equal channels,
+    filtered with itself as guidance, any channel of the result)."""
+    _, r8 = ops.cnn_reflectance_u8(images, weights=weights, want_float=False)
+    r1 = r8.unsqueeze(-1)
+    out = ops.joint_bilateral_u8(r1, r1, -1, sigma_color, sigma_spatial, grey_as_bgr=True)
+    return r8, out.squeeze(-1)
+
+
 def decompose_image(filename_in, path_out, caffemodel=None):
     """Predict reflectance intensity for one image file and write `<base>-r.png`,
     `<base>-r_colorized.png`, `<base>-s_colorized.png`

@@ -18,8 +18,12 @@ def _chk_images(t, name, torch):
 
 
 def joint_bilateral_u8(joint, src, d, sigma_color, sigma_space, border=_ffi.BORDER_DEFAULT,
-                       flags=0, out=None):
-    """Batched cv2.ximgproc.jointBilateralFilter(joint, src, d, sigmaColor, sigmaSpace)."""
+                       flags=0, out=None, grey_as_bgr=False):
+    """Batched cv2.ximgproc.jointBilateralFilter(joint, src, d, sigmaColor, sigmaSpace).
+    grey_as_bgr: a 1-channel joint is filtered as the 3-equal-channel image cv2.imread would
+    have produced from it (no replicated copy is made)."""
+    if grey_as_bgr:
+        flags |= _ffi.JBF_GREY_AS_BGR
     torch = _ffi.require_gpu()
     lib = _ffi.load_library()
     _chk_images(joint, "joint", torch)

@@ -212,6 +212,34 @@ def test_cnn_matches_oracle_and_golden(env):
     assert np.array_equal(out, r[0].cpu().numpy())
 
 
+def test_grey_as_bgr_and_fused_chain(env):
+    """1-channel joint/src with RF_JBF_GREY_AS_BGR == the 3-equal-channel images cv2.imread
+    would hand to the filter; decompose_and_filter_batch == the two-CLI chain."""
+    from tests import synth
+    rf, co, torch = env
+    grey = synth.reflectance_like_u8(150, 203, seed=5)[:, :, 0]
+    joint = synth.scene_u8(150, 203, seed=6)[:, :, 1]
+    g1, j1 = _dev(torch, grey[:, :, None], joint[:, :, None])
+    want = co.joint_bilateral_filter(np.repeat(joint[:, :, None], 3, 2),
+                                     np.repeat(grey[:, :, None], 3, 2), -1, 20, 22)
+    for flags in (0, rf._ffi.JBF_FORCE_GENERIC, 1 << 8):
+        got = rf.ops.joint_bilateral_u8(j1, g1, -1, 20, 22, flags=flags, grey_as_bgr=True)
+        assert np.array_equal(got[0, :, :, 0].cpu().numpy(), want[:, :, 0]), flags
+    # without the flag a 1-channel joint keeps OpenCV's 1-channel semantics (distance |d|)
+    plain = rf.ops.joint_bilateral_u8(j1, g1, -1, 20, 22)
+    assert np.array_equal(plain[0, :, :, 0].cpu().numpy(),
+                          co.joint_bilateral_filter(joint, grey, -1, 20, 22))
+    scenes = np.stack([synth.scene_u8(120, 171, seed=s) for s in (1, 2, 3)])
+    r8, filt = rf.decompose_and_filter_batch(torch.from_numpy(scenes).cuda())
+    w = rf.weights.load_weights()
+    for i in range(3):
+        _, want_r8 = co.cnn_reflectance(scenes[i], w)
+        assert np.array_equal(r8[i].cpu().numpy(), want_r8)
+        r3 = np.repeat(want_r8[:, :, None], 3, 2)
+        assert np.array_equal(filt[i].cpu().numpy(),
+                              co.joint_bilateral_filter(r3, r3.copy(), -1, 20, 22)[:, :, 0])
+
+
 # ------------------------------------------------------------------------------ CLI chain
 def test_cli_chain_bf_cnn_cnn(env, tmp_path):
     """BASELINE config C3 in miniature: decompose CLI -> `-r.png` -> filter CLI with the

@@ -69,11 +69,7 @@ def main():
     ms_bf = timed(torch, lambda: rf.ops.joint_bilateral_u8(r3b, r3, -1, 20, 22, out=o))
     out["bf_cnn_cnn_iiw"] = {"ms": ms_bf, "mp_per_s": n * h * w / 1e6 / (ms_bf * 1e-3), "batch": n}
 
-    def chain():
-        _, q = rf.get_reflectance_batch(scene)
-        q3 = q.unsqueeze(-1).expand(-1, -1, -1, 3).contiguous()
-        rf.ops.joint_bilateral_u8(q3.clone(), q3, -1, 20, 22, out=o)
-    ms = timed(torch, chain)
+    ms = timed(torch, lambda: rf.decompose_and_filter_batch(scene))
     out["c3_chain_iiw"] = {"ms": ms, "mp_per_s": n * h * w / 1e6 / (ms * 1e-3), "batch": n,
                            "ms_per_image": ms / n}
     print(json.dumps(out, indent=1))
