@@ -35,6 +35,8 @@ def init_distributed(backend=None):
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
             if backend is None:
+                backend = os.environ.get("RF_DIST_BACKEND")
+            if backend is None:
                 import torch
                 backend = "nccl" if torch.cuda.is_available() else "gloo"
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -43,8 +45,12 @@ def init_distributed(backend=None):
 
 def barrier(world_size):
     if world_size > 1:
+        import torch
         import torch.distributed as dist
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
 
 
 def reduce_job(local_units, local_seconds, world_size, device=None):
@@ -53,7 +59,7 @@ def reduce_job(local_units, local_seconds, world_size, device=None):
         return float(local_units), float(local_seconds)
     import torch
     import torch.distributed as dist
-    dev = device if device is not None else "cpu"
+    dev = device if device is not None and dist.get_backend() != "gloo" else "cpu"
     units = torch.tensor([float(local_units)], dtype=torch.float64, device=dev)
     secs = torch.tensor([float(local_seconds)], dtype=torch.float64, device=dev)
     dist.all_reduce(units, op=dist.ReduceOp.SUM)
