@@ -772,15 +772,15 @@ __global__ __launch_bounds__(16 * TH) void jbf_tiled2_kernel(
 // ------------------------------------------------------------------------------------------
 constexpr int kT64Lds = 163840;
 
-template <int SCN, int GREP, int CREP>
+template <int SCN, int GREP, int CREP, int TLW>
 __global__ __launch_bounds__(1024) void jbf_tile64_kernel(
     const uint8_t *__restrict__ joint, const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
     int h, int w, int jcn, int radius, int border, const float *__restrict__ lut, int nz,
     const int *__restrict__ hwtab, const float *__restrict__ swsym, int sw_len, int tiles_x,
-    int tiles_per_img, int flags)
+    int tiles_per_img, int flags, int crows)
 {
     constexpr int NT = 1024;
-    constexpr int TLW = kTlw2;
+    static_assert(TLW % 32 == 16, "row pitch keeps 16-lane rows on disjoint banks");
     constexpr int Q4 = TLW / 4;
     extern __shared__ __align__(16) unsigned char smem[];
     volatile int *flag_word = reinterpret_cast<volatile int *>(smem);
@@ -855,12 +855,13 @@ __global__ __launch_bounds__(1024) void jbf_tile64_kernel(
     }
 
     if constexpr (SCN == 3) {
-        // ---- colour src: two 32-row halves with 8-byte texels ----
+        // ---- colour src: 64/crows passes of crows rows with 8-byte texels (crows = 32 when
+        //      the LDS allows it, i.e. two halves run by threads 0..511) ----
         uint2 *tile8 = reinterpret_cast<uint2 *>(tile_raw);
         float *lut_c = reinterpret_cast<float *>(smem + kT64Lds - nz * CREP * 4);
-        const int tlh8 = 32 + 2 * radius;
-        for (int half = 0; half < 2; half++) {
-            const int y0 = tile_y0 + 32 * half;
+        const int tlh8 = crows + 2 * radius;
+        for (int half = 0; half * crows < 64; half++) {
+            const int y0 = tile_y0 + crows * half;
             if (y0 >= h)
                 break;
             __syncthreads();  // everyone is done with the previous contents of the tile
@@ -877,7 +878,7 @@ __global__ __launch_bounds__(1024) void jbf_tile64_kernel(
                     tile8[ry * TLW + u * Q4 + k] = make_uint2(jv[u], sv[u]);
             }
             __syncthreads();
-            if (tid < 512) {
+            if (tid < 16 * crows) {
                 uint32_t jc[kPix];
 #pragma unroll
                 for (int p = 0; p < kPix; p++) {
@@ -987,16 +988,28 @@ int lds_oob_reads_zero(int dev, bool *ok)
 }
 
 // LDS needed by jbf_tile64_kernel for grey / colour tiles with the given LUT replication.
-bool tile64_fits(const JbfTables &t, int nz, int grep, int crep, int scn)
+// Rows per colour pass (32, 16 or 8) that fit, or 0.
+int tile64_fits(const JbfTables &t, int nz, int grep, int crep, int scn, int tlw)
 {
+    if (2 * t.r4 + kTileW + 8 > tlw)
+        return 0;
     const size_t sw_bytes = 16 + (((size_t)(t.radius + 1) * t.sw_len * 4 + 15) & ~(size_t)15);
-    const size_t grey = sw_bytes + (size_t)kTlw2 * (64 + 2 * t.radius) * 4 + (size_t)nz * grep * 4;
-    const size_t col = sw_bytes + (size_t)kTlw2 * (32 + 2 * t.radius) * 8 + (size_t)nz * crep * 4;
-    return grey <= (size_t)kT64Lds && (scn == 1 || col <= (size_t)kT64Lds);
+    const size_t grey = sw_bytes + (size_t)tlw * (64 + 2 * t.radius) * 4 + (size_t)nz * grep * 4;
+    if (grey > (size_t)kT64Lds)
+        return 0;
+    if (scn == 1)
+        return 32;
+    for (int crows = 32; crows >= 8; crows >>= 1) {
+        const size_t col =
+            sw_bytes + (size_t)tlw * (crows + 2 * t.radius) * 8 + (size_t)nz * crep * 4;
+        if (col <= (size_t)kT64Lds)
+            return crows;
+    }
+    return 0;
 }
 
-template <int SCN, int GREP, int CREP>
-int launch_tile64(const JbfTables &t, int nz, const uint8_t *joint, const uint8_t *src,
+template <int SCN, int GREP, int CREP, int TLW>
+int launch_tile64(const JbfTables &t, int nz, int crows, const uint8_t *joint, const uint8_t *src,
                   uint8_t *dst, int n, int h, int w, int jcn, int border, int flags,
                   hipStream_t stream)
 {
@@ -1004,12 +1017,12 @@ int launch_tile64(const JbfTables &t, int nz, const uint8_t *joint, const uint8_
     const long long blocks = (long long)tiles_x * tiles_y * n;
     if (blocks > 0x7fffffffLL)
         return fail(RF_E_UNSUPPORTED, "rf_jbf_u8: batch too large for one launch");
-    auto kern = jbf_tile64_kernel<SCN, GREP, CREP>;
+    auto kern = jbf_tile64_kernel<SCN, GREP, CREP, TLW>;
     RF_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      kT64Lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(1024), kT64Lds, stream, joint, src, dst,
                        h, w, jcn, t.radius, border, t.d_lut, nz, t.d_hw, t.d_swsym, t.sw_len,
-                       tiles_x, tiles_x * tiles_y, flags);
+                       tiles_x, tiles_x * tiles_y, flags, crows);
     return RF_OK;
 }
 
@@ -1076,7 +1089,7 @@ extern "C" int rf_jbf_u8(const uint8_t *joint, const uint8_t *src, uint8_t *dst,
     // src; the clamp-free 8x table is next
     // tune 7 forces the 64x64 kernel, tune 1..6 the 64xTH kernel
     bool done = false;
-    if (!(flags & RF_JBF_FORCE_GENERIC) && t.r4 <= 36 && (tune == 0 || tune == 7)) {
+    if (!(flags & RF_JBF_FORCE_GENERIC) && t.r4 <= 52 && (tune == 0 || tune == 7)) {
         bool oob_ok = false;
         rc = lds_oob_reads_zero(t.device, &oob_ok);
         if (rc != RF_OK)
@@ -1084,19 +1097,26 @@ extern "C" int rf_jbf_u8(const uint8_t *joint, const uint8_t *src, uint8_t *dst,
         // table entries before the zero tail (the whole table if it has none)
         const int nz = t.lut_len < 256 * joint_cn ? t.lut_len - 1 : t.lut_len;
         if (oob_ok) {
-#define RF_T64(G_, C_)                                                                         \
-    if (!done && tile64_fits(t, nz, G_, C_, src_cn)) {                                         \
-        rc = src_cn == 3 ? launch_tile64<3, G_, C_>(t, nz, joint, src, dst, n, h, w, jcn_kernel, \
-                                                    border, flags, stream)                     \
-                         : launch_tile64<1, G_, C_>(t, nz, joint, src, dst, n, h, w, jcn_kernel, \
-                                                    border, flags, stream);                    \
-        if (rc != RF_OK)                                                                       \
-            return rc;                                                                         \
-        done = true;                                                                           \
+            // row pitch 144 serves radius <= 36, 176 radius <= 52 (colour tiles of the wide
+            // pitch run in 16- or 8-row passes)
+#define RF_T64(G_, C_, W_)                                                                        \
+    if (!done && tile64_fits(t, nz, G_, C_, src_cn, W_) > 0) {                                    \
+        const int crows_ = tile64_fits(t, nz, G_, C_, src_cn, W_);                                \
+        rc = src_cn == 3 ? launch_tile64<3, G_, C_, W_>(t, nz, crows_, joint, src, dst, n, h, w,  \
+                                                        jcn_kernel, border, flags, stream)        \
+                         : launch_tile64<1, G_, C_, W_>(t, nz, crows_, joint, src, dst, n, h, w,  \
+                                                        jcn_kernel, border, flags, stream);       \
+        if (rc != RF_OK)                                                                          \
+            return rc;                                                                            \
+        done = true;                                                                              \
     }
-            RF_T64(32, 16)
-            RF_T64(16, 8)
-            RF_T64(8, 4)
+            RF_T64(32, 16, 144)
+            RF_T64(16, 8, 144)
+            RF_T64(8, 4, 144)
+            RF_T64(32, 16, 176)
+            RF_T64(32, 4, 176)
+            RF_T64(16, 8, 176)
+            RF_T64(8, 4, 176)
 #undef RF_T64
         }
     }

@@ -99,6 +99,20 @@ def test_jbf_border_types_flags_and_generic_kernel(env):
     assert np.array_equal(rf.ops.joint_bilateral_u8(j, s, -1, 20, 40)[0].cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("ss,sc", [(28, 15), (34.5, 20), (24.3, 9)])
+def test_jbf_wide_radius_tiles(env, ss, sc):
+    """radius 42 / 52 / 36: the 176-texel row pitch (grey and colour tiles) and the pitch
+    boundary; README.md:63 of the reference uses c15 s28."""
+    from tests import synth
+    rf, co, torch = env
+    joint = synth.flat_guide_u8(100, 150, seed=int(ss), cells=30)
+    grey = synth.reflectance_like_u8(100, 150, seed=3)
+    colour = synth.scene_u8(100, 150, seed=4)
+    for src in (grey, colour):
+        got = rf.ximgproc.jointBilateralFilter(joint, src, -1, sc, ss)
+        assert np.array_equal(got, co.joint_bilateral_filter(joint, src, -1, sc, ss))
+
+
 def test_jbf_known_answers_on_device(env):
     rf, co, torch = env
     rng = np.random.default_rng(0)
