@@ -193,6 +193,8 @@ extern "C" int rf_cnn_reflectance_u8(const uint8_t *bgr, float *r_out, uint8_t *
                                      void *stream_)
 {
     using namespace rf;
+    if (n == 0)  // an empty batch is valid whatever the (possibly NULL) pointers are
+        return RF_OK;
     static_assert(kPackedFloats == RF_CNN_NPARAMS, "packed layout is a permutation");
     if (!bgr || !weights || !srgb_lut || (!r_out && !r_u8_out))
         return fail(RF_E_BADARG, "rf_cnn_reflectance_u8: NULL pointer");

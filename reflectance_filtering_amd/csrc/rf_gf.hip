@@ -373,6 +373,8 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
                         void *workspace, size_t workspace_bytes, void *stream_)
 {
     using namespace rf;
+    if (n == 0)  // an empty batch is valid whatever the (possibly NULL) pointers are
+        return RF_OK;
     if (!guide || !src || !dst || !workspace)
         return fail(RF_E_BADARG, "rf_gf_u8: NULL pointer");
     if (n < 0 || h <= 0 || w <= 0 || iterations < 1)

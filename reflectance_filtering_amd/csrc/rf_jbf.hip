@@ -1043,6 +1043,8 @@ extern "C" int rf_jbf_u8(const uint8_t *joint, const uint8_t *src, uint8_t *dst,
                          double sigma_space, int border, int flags, void *stream_)
 {
     using namespace rf;
+    if (n == 0)  // an empty batch is valid whatever the (possibly NULL) pointers are
+        return RF_OK;
     if (!joint || !src || !dst)
         return fail(RF_E_BADARG, "rf_jbf_u8: NULL image pointer");
     if (n < 0 || h <= 0 || w <= 0)

@@ -154,6 +154,30 @@ def test_jbf_full_1080p_locality_and_batch(env):
     #  the contract and it is not flip-symmetric)
 
 
+def test_empty_batch_aliasing_and_shutdown(env):
+    from tests import synth
+    rf, co, torch = env
+    lib = rf._ffi.load_library()
+    empty = torch.empty((0, 32, 32, 3), dtype=torch.uint8, device="cuda")
+    assert rf.ops.joint_bilateral_u8(empty, empty.clone(), -1, 20, 22).shape == (0, 32, 32, 3)
+    assert rf.ops.guided_filter_u8(empty, empty.clone(), 5, 1.0).shape == (0, 32, 32, 3)
+    img = torch.from_numpy(synth.scene_u8(40, 40, seed=1)[None]).cuda()
+    with pytest.raises(ValueError):
+        rf.ops.joint_bilateral_u8(img, img.clone(), -1, 20, 22, out=img)   # dst aliases joint
+    with pytest.raises(ValueError):
+        rf.ops.joint_bilateral_u8(img[..., :2].contiguous(), img, -1, 20, 22)  # 2 channels
+    with pytest.raises(ValueError):
+        rf.ops.guided_filter_u8(img[..., :1].contiguous(), img, 5, 1.0)    # 1-channel guide
+    a = rf.ops.joint_bilateral_u8(img, img.clone(), -1, 20, 6)
+    assert lib.rf_shutdown() == 0          # parameter tables are rebuilt on demand
+    b = rf.ops.joint_bilateral_u8(img, img.clone(), -1, 20, 6)
+    assert torch.equal(a, b)
+    # sigma <= 0 is OpenCV's "becomes 1" at the C boundary (the Python API rejects it earlier)
+    c = rf.ops.joint_bilateral_u8(img, img.clone(), 5, 0.0, -3.0)
+    want = co.joint_bilateral_filter(img[0].cpu().numpy(), img[0].cpu().numpy(), 5, 1.0, 1.0)
+    assert np.array_equal(c[0].cpu().numpy(), want)
+
+
 # ------------------------------------------------------------------------------ GF
 @pytest.mark.parametrize("h,w,r,eps", [(256, 256, 52, 7.0), (256, 256, 45, 3.0), (130, 517, 9, 3.0),
                                        (64, 700, 20, 0.5), (37, 41, 45, 3.0), (90, 64, 1, 1e-3)])
