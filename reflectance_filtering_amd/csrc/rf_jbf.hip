@@ -345,6 +345,8 @@ __device__ inline uint32_t lds_addr(const void *p)
 #define RF_LDS_READ_B32(dst, addr) asm volatile("ds_read_b32 %0, %1" : "=v"(dst) : "v"(addr))
 #define RF_LDS_READ_B32_OFF(dst, addr, off) \
     asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define RF_LDS_READ_U16_OFF(dst, addr, off) \
+    asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 
 // Accumulates all taps of one lane's 4 outputs.  NCH = channels accumulated (3, or 1 when the
 // src is single-channel or every src texel of the tile is grey: identical bits, a third of the
@@ -354,12 +356,15 @@ __device__ inline uint32_t lds_addr(const void *p)
 // workgroup's LDS allocation, where ds_read returns 0).  sum/wsum must be zero on entry.
 template <int NCH, int LUTREP, bool CLAMP, int TLW, int TB>
 __device__ __forceinline__ void jbf_tap_loop(uint32_t lut_lane_addr, uint32_t sw_addr0,
-                                             uint32_t tile_lane_addr, const uint32_t (&jc)[kPix],
-                                             uint32_t amax, int ty, int radius, int r4, int sw_len,
+                                             uint32_t tile_lane_addr, uint32_t plane_b_lane_addr,
+                                             const uint32_t (&jc)[kPix], uint32_t amax, int ty,
+                                             int radius, int r4, int sw_len,
                                              const int *__restrict__ hwtab, float (&sum)[kPix][NCH],
                                              float (&wsum)[kPix])
 {
-    static_assert(TB == 8 || (TB == 4 && NCH == 1), "4-byte texels carry one src channel");
+    static_assert((TB == 8) || (TB == 4 && NCH == 1) || (TB == 6 && NCH == 3),
+                  "4-byte texels carry one src channel, 6-byte ones three");
+    constexpr int TA = TB == 6 ? 4 : TB;  // bytes per texel in the main plane
     constexpr int Q4 = TLW / 4;
     using texel_t = typename std::conditional<TB == 8, uint2v, uint32_t>::type;
     auto joint_of = [](const texel_t &t) -> uint32_t {
@@ -378,11 +383,14 @@ __device__ __forceinline__ void jbf_tap_loop(uint32_t lut_lane_addr, uint32_t sw
             RF_LDS_READ_B32(g[p], a);
         }
     };
-#define RF_READ_TEXEL(dst, addr, off_texels)          \
-    if constexpr (TB == 8) {                          \
-        RF_LDS_READ_B64(dst, addr, (off_texels) * 8); \
-    } else {                                          \
-        RF_LDS_READ_B32_OFF(dst, addr, (off_texels) * 4); \
+    // TB == 6: second plane of 2-byte texels {G src, R src}; U = ring slot
+#define RF_READ_TEXEL(U, off_texels)                                   \
+    if constexpr (TB == 8) {                                           \
+        RF_LDS_READ_B64(tq[U], ta, (off_texels) * 8);                  \
+    } else {                                                           \
+        RF_LDS_READ_B32_OFF(tq[U], ta, (off_texels) * 4);              \
+        if constexpr (TB == 6)                                         \
+            RF_LDS_READ_U16_OFF(tqb[U], tb, (off_texels) * 2);         \
     }
 
     for (int i = -radius; i <= radius; i++) {
@@ -391,8 +399,9 @@ __device__ __forceinline__ void jbf_tap_loop(uint32_t lut_lane_addr, uint32_t sw
         const int ai = i < 0 ? -i : i;
         // column c = 4*gq + u - hw4 (gq = 0 .. hw4/2): tile column X = c + r4 + 4*tx, i.e. texel
         // address = ta + (u*Q4 + gq)*TB with ta the per-lane address of (row, group 0, u = 0)
-        uint32_t ta = tile_lane_addr +
-                      (uint32_t)(((ty + i + radius) * TLW + ((r4 - hw4) >> 2)) * TB);
+        const uint32_t texel0 = (uint32_t)((ty + i + radius) * TLW + ((r4 - hw4) >> 2));
+        uint32_t ta = tile_lane_addr + texel0 * TA;
+        uint32_t tb = plane_b_lane_addr + texel0 * 2;
         // weight of tap (i, j) = swc[j] = swc[-j]; group gq needs swc[hw4 - 4*gq - 4 .. +3]
         uint32_t wa_addr = sw_addr0 + (uint32_t)((ai * sw_len + (r4 + 8) + hw4 - 4) * 4);
         const int ngroups = (hw4 >> 1) + 1;
@@ -402,17 +411,18 @@ __device__ __forceinline__ void jbf_tap_loop(uint32_t lut_lane_addr, uint32_t sw
         // of that step, so nothing is in flight across the loop back-edge (a value in flight
         // there would be copied by the compiler's phi moves before it has landed).
         texel_t tq[4];
+        uint32_t tqb[4] = {0u, 0u, 0u, 0u};  // second plane (TB == 6 only)
         float4v wna, wnb;
         float gg[2][kPix];
-        RF_READ_TEXEL(tq[0], ta, 0)
-        RF_READ_TEXEL(tq[1], ta, Q4)
+        RF_READ_TEXEL(0, 0)
+        RF_READ_TEXEL(1, Q4)
         RF_LDS_READ_B128(wna, wa_addr, 0);
         RF_LDS_READ_B128(wnb, wa_addr, 16);
-        asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(tq[0]));
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(tq[0]), "+v"(tq[1]), "+v"(tqb[0]), "+v"(tqb[1]), "+v"(wna), "+v"(wnb));
         issue_gathers(joint_of(tq[0]), gg[0]);
         asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(tq[1]), "+v"(wna), "+v"(wnb), "+v"(gg[0][0]), "+v"(gg[0][1]),
-                       "+v"(gg[0][2]), "+v"(gg[0][3]));
+                     : "+v"(gg[0][0]), "+v"(gg[0][1]), "+v"(gg[0][2]), "+v"(gg[0][3]));
 
 #define RF_ACCUM(U)                                                                  \
     {                                                                                \
@@ -426,6 +436,10 @@ __device__ __forceinline__ void jbf_tap_loop(uint32_t lut_lane_addr, uint32_t sw
             }                                                                        \
         } else {                                                                     \
             s[0] = (float)(tq[(U)] >> 24);                                           \
+            if constexpr (TB == 6) {                                                 \
+                s[1] = (float)(tqb[(U)] & 0xff);                                     \
+                s[2] = (float)((tqb[(U)] >> 8) & 0xff);                              \
+            }                                                                        \
         }                                                                            \
         _Pragma("unroll") for (int p = 0; p < kPix; p++)                             \
         {                                                                            \
@@ -453,7 +467,7 @@ __device__ __forceinline__ void jbf_tap_loop(uint32_t lut_lane_addr, uint32_t sw
         // one column: issue texel(+2) and gathers(+1), accumulate column +0 underneath them,
         // then release what was issued
 #define RF_STEP(U)                                                                            \
-    RF_READ_TEXEL(tq[((U) + 2) & 3], ta, RF_TEXEL_OFF(U))                                     \
+    RF_READ_TEXEL(((U) + 2) & 3, RF_TEXEL_OFF(U))                                             \
     issue_gathers(joint_of(tq[((U) + 1) & 3]), gg[((U) + 1) & 1]);                            \
     __builtin_amdgcn_sched_barrier(0);                                                        \
     RF_ACCUM(U)                                                                               \
@@ -461,9 +475,9 @@ __device__ __forceinline__ void jbf_tap_loop(uint32_t lut_lane_addr, uint32_t sw
     RF_PIN_ACC()                                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                        \
     asm volatile("s_waitcnt lgkmcnt(0)"                                                       \
-                 : "+v"(tq[((U) + 2) & 3]), "+v"(gg[((U) + 1) & 1][0]),                       \
-                   "+v"(gg[((U) + 1) & 1][1]), "+v"(gg[((U) + 1) & 1][2]),                    \
-                   "+v"(gg[((U) + 1) & 1][3]));                                               \
+                 : "+v"(tq[((U) + 2) & 3]), "+v"(tqb[((U) + 2) & 3]),                         \
+                   "+v"(gg[((U) + 1) & 1][0]), "+v"(gg[((U) + 1) & 1][1]),                    \
+                   "+v"(gg[((U) + 1) & 1][2]), "+v"(gg[((U) + 1) & 1][3]));                   \
     __builtin_amdgcn_sched_barrier(0);
 
         for (int gq = 0; gq < ngroups; gq++) {
@@ -474,7 +488,7 @@ __device__ __forceinline__ void jbf_tap_loop(uint32_t lut_lane_addr, uint32_t sw
             RF_STEP(1)
             RF_STEP(2)
             // u = 3 also fetches the next group's weight window
-            RF_READ_TEXEL(tq[1], ta, RF_TEXEL_OFF(3))
+            RF_READ_TEXEL(1, RF_TEXEL_OFF(3))
             issue_gathers(joint_of(tq[0]), gg[0]);
             wa_addr -= 16;
             RF_LDS_READ_B128(wna, wa_addr, 0);
@@ -485,10 +499,11 @@ __device__ __forceinline__ void jbf_tap_loop(uint32_t lut_lane_addr, uint32_t sw
             RF_PIN_ACC()
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(tq[1]), "+v"(wna), "+v"(wnb), "+v"(gg[0][0]), "+v"(gg[0][1]),
-                           "+v"(gg[0][2]), "+v"(gg[0][3]));
+                         : "+v"(tq[1]), "+v"(tqb[1]), "+v"(wna), "+v"(wnb), "+v"(gg[0][0]),
+                           "+v"(gg[0][1]), "+v"(gg[0][2]), "+v"(gg[0][3]));
             __builtin_amdgcn_sched_barrier(0);
-            ta += TB;
+            ta += TA;
+            tb += 2;
         }
 #undef RF_STEP
 #undef RF_PIN_ACC
@@ -654,6 +669,7 @@ __device__ __forceinline__ void jbf_tap_loop_grey4(uint32_t lut_lane_addr, uint3
 #undef RF_LDS_READ_B128
 #undef RF_LDS_READ_B32
 #undef RF_LDS_READ_B32_OFF
+#undef RF_LDS_READ_U16_OFF
 
 template <int SCN, int TH, int LUTREP, bool CLAMP>
 __global__ __launch_bounds__(16 * TH) void jbf_tiled2_kernel(
@@ -731,7 +747,7 @@ __global__ __launch_bounds__(16 * TH) void jbf_tiled2_kernel(
             sum[p][c] = 0.f;
     }
     if (SCN == 3 && !all_grey) {
-        jbf_tap_loop<SCN, LUTREP, CLAMP, TLW, 8>(lut_lane_addr, sw_addr0, tile_lane_addr, jc, amax,
+        jbf_tap_loop<SCN, LUTREP, CLAMP, TLW, 8>(lut_lane_addr, sw_addr0, tile_lane_addr, 0u, jc, amax,
                                               ty, radius, r4, sw_len, hwtab, sum, wsum);
     } else {
         // single-channel accumulation; for a grey 3-channel src the three sums are the same
@@ -740,7 +756,7 @@ __global__ __launch_bounds__(16 * TH) void jbf_tiled2_kernel(
 #pragma unroll
         for (int p = 0; p < kPix; p++)
             sum1[p][0] = 0.f;
-        jbf_tap_loop<1, LUTREP, CLAMP, TLW, 8>(lut_lane_addr, sw_addr0, tile_lane_addr, jc, amax, ty,
+        jbf_tap_loop<1, LUTREP, CLAMP, TLW, 8>(lut_lane_addr, sw_addr0, tile_lane_addr, 0u, jc, amax, ty,
                                             radius, r4, sw_len, hwtab, sum1, wsum);
 #pragma unroll
         for (int p = 0; p < kPix; p++)
@@ -845,7 +861,7 @@ __global__ __launch_bounds__(1024) void jbf_tile64_kernel(
         const uint32_t lut_lane_addr = lds_addr(lut_g) + (uint32_t)(tid & (GREP - 1)) * 4u;
         const uint32_t tile_lane_addr = lds_addr(tile4) + (uint32_t)tx * 4u;
         if (flags & 0x2000)  // benchmark aid: compiler-scheduled loop instead of the asm one
-            jbf_tap_loop<1, GREP, false, TLW, 4>(lut_lane_addr, sw_addr0, tile_lane_addr, jc, 0u,
+            jbf_tap_loop<1, GREP, false, TLW, 4>(lut_lane_addr, sw_addr0, tile_lane_addr, 0u, jc, 0u,
                                                  ty, radius, r4, sw_len, hwtab, sum1, wsum);
         else
             jbf_tap_loop_grey4<GREP, TLW>(lut_lane_addr, sw_addr0, tile_lane_addr, jc, ty, radius,
@@ -855,6 +871,45 @@ __global__ __launch_bounds__(1024) void jbf_tile64_kernel(
     }
 
     if constexpr (SCN == 3) {
+        if (crows == 64) {
+            // ---- colour src, one pass: the grey-packed plane already holds {B,G,R joint, B src};
+            //      a second plane of 2-byte texels adds {G src, R src}: 6 bytes per texel, all
+            //      1024 threads stay busy (4 waves/SIMD) ----
+            uint16_t *plane_b = reinterpret_cast<uint16_t *>(tile_raw + (size_t)tlh * TLW * 4);
+            float *lut_c = reinterpret_cast<float *>(smem + kT64Lds - nz * CREP * 4);
+            __syncthreads();  // the grey LUT region is about to be overwritten
+            for (int i = tid; i < nz * CREP; i += NT)
+                lut_c[i] = lut[i / CREP];
+            for (int item = tid; item < tlh * Q4; item += NT) {
+                const int ry = item / Q4, k = item - ry * Q4;
+                const int gy = border_interpolate(tile_y0 - radius + ry, h, border);
+                uint32_t jv[4], sv[4];
+                load_tile_quad(joint, src, img, gy, tile_x0 - r4 + 4 * k, w, jcn, 3, border, jv, sv);
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    plane_b[ry * TLW + u * Q4 + k] = (uint16_t)(sv[u] >> 8);
+            }
+            __syncthreads();
+            uint32_t jc[kPix];
+#pragma unroll
+            for (int p = 0; p < kPix; p++) {
+                const int X = 4 * tx + p + r4;
+                jc[p] = tile4[(ty + radius) * TLW + (X & 3) * Q4 + (X >> 2)] & 0x00ffffffu;
+            }
+            float sum[kPix][3], wsum[kPix];
+#pragma unroll
+            for (int p = 0; p < kPix; p++) {
+                wsum[p] = 0.f;
+                sum[p][0] = sum[p][1] = sum[p][2] = 0.f;
+            }
+            const uint32_t lut_lane_addr = lds_addr(lut_c) + (uint32_t)(tid & (CREP - 1)) * 4u;
+            jbf_tap_loop<3, CREP, false, TLW, 6>(lut_lane_addr, sw_addr0,
+                                                 lds_addr(tile4) + (uint32_t)tx * 4u,
+                                                 lds_addr(plane_b) + (uint32_t)tx * 2u, jc, 0u, ty,
+                                                 radius, r4, sw_len, hwtab, sum, wsum);
+            store_quad<3, 3>(dst, img, tile_y0 + ty, tile_x0 + 4 * tx, h, w, sum, wsum, flags);
+            return;
+        }
         // ---- colour src: 64/crows passes of crows rows with 8-byte texels (crows = 32 when
         //      the LDS allows it, i.e. two halves run by threads 0..511) ----
         uint2 *tile8 = reinterpret_cast<uint2 *>(tile_raw);
@@ -893,7 +948,7 @@ __global__ __launch_bounds__(1024) void jbf_tile64_kernel(
                 }
                 const uint32_t lut_lane_addr = lds_addr(lut_c) + (uint32_t)(tid & (CREP - 1)) * 4u;
                 const uint32_t tile_lane_addr = lds_addr(tile8) + (uint32_t)tx * 8u;
-                jbf_tap_loop<3, CREP, false, TLW, 8>(lut_lane_addr, sw_addr0, tile_lane_addr, jc,
+                jbf_tap_loop<3, CREP, false, TLW, 8>(lut_lane_addr, sw_addr0, tile_lane_addr, 0u, jc,
                                                      0u, ty, radius, r4, sw_len, hwtab, sum, wsum);
                 store_quad<3, 3>(dst, img, y0 + ty, tile_x0 + 4 * tx, h, w, sum, wsum, flags);
             }
@@ -988,7 +1043,8 @@ int lds_oob_reads_zero(int dev, bool *ok)
 }
 
 // LDS needed by jbf_tile64_kernel for grey / colour tiles with the given LUT replication.
-// Rows per colour pass (32, 16 or 8) that fit, or 0.
+// Rows per colour pass that fit (64 = one pass with 6-byte texels; 32, 16, 8 = passes with
+// 8-byte texels), or 0.
 int tile64_fits(const JbfTables &t, int nz, int grep, int crep, int scn, int tlw)
 {
     if (2 * t.r4 + kTileW + 8 > tlw)
@@ -999,6 +1055,9 @@ int tile64_fits(const JbfTables &t, int nz, int grep, int crep, int scn, int tlw
         return 0;
     if (scn == 1)
         return 32;
+    // colour tiles in one pass: a 4-byte and a 2-byte plane of the full 64-row tile
+    if (sw_bytes + (size_t)tlw * (64 + 2 * t.radius) * 6 + (size_t)nz * crep * 4 <= (size_t)kT64Lds)
+        return 64;
     for (int crows = 32; crows >= 8; crows >>= 1) {
         const size_t col =
             sw_bytes + (size_t)tlw * (crows + 2 * t.radius) * 8 + (size_t)nz * crep * 4;
