@@ -100,6 +100,35 @@ def test_jbf_image_smaller_than_radius_and_flags():
         co.joint_bilateral_filter(joint[:, :, :2], src, -1, 25, 4)
 
 
+def test_jbf_c_oracle_matches_second_restatement_bitwise():
+    """rf_oracle.c against the numpy spelling of the same operation order (oracle/t1_numpy.py)."""
+    from oracle import t1_numpy as t1
+    for (h, w, jcn, scn, sc, ss) in ((19, 23, 3, 3, 20, 4), (12, 30, 1, 3, 35, 3), (9, 7, 3, 1, 20, 22)):
+        joint = synth.scene_u8(h, w, seed=h)
+        src = synth.scene_u8(h, w, seed=w)
+        joint = joint if jcn == 3 else joint[:, :, 0]
+        src = src if scn == 3 else src[:, :, 2]
+        assert np.array_equal(co.joint_bilateral_filter(joint, src, -1, sc, ss),
+                              t1.joint_bilateral_f32seq(joint, src, sc, ss))
+    assert np.array_equal(
+        co.joint_bilateral_filter(joint, src, 7, 20, 4, flags=co.FLAG_TRUE_DIVISION),
+        t1.joint_bilateral_f32seq(joint, src, 20, 4, d=7, true_division=True))
+
+
+def test_gf_c_oracle_matches_second_restatement_bitwise():
+    from oracle import t1_numpy as t1
+    rng = np.random.default_rng(8)
+    plane = (rng.standard_normal((23, 31)) * 40).astype(np.float32)
+    for r in (1, 5, 40):
+        assert np.array_equal(co.box_mean_f32(plane, r), t1.box_mean_seq(plane, r))
+    guide = synth.flat_guide_u8(40, 52, seed=3, cells=9)
+    src = synth.reflectance_like_u8(40, 52, seed=4)
+    for r, eps in ((6, 3.0), (45, 7.0), (2, 1e-3)):
+        want_u8, want_f = t1.guided_filter_f32seq(guide, src, r, eps)
+        got_u8, got_f = co.guided_filter(guide, src, r, eps, return_float=True)
+        assert np.array_equal(got_f, want_f) and np.array_equal(got_u8, want_u8)
+
+
 # ------------------------------------------------------------------ guided filter
 def test_box_mean_matches_float64_and_is_exact_on_integers():
     rng = np.random.default_rng(4)
