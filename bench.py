@@ -77,11 +77,35 @@ def synth_batch(torch, n, h, w, seed, device):
     return joint.contiguous(), src.contiguous()
 
 
+def usable_cores():
+    """CPUs this process may actually use: affinity mask, capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as fh:
+                parts = fh.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                quota = int(parts[0])
+                if quota > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh2:
+                        n = min(n, max(1, quota // int(fh2.read())))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(joint0, src0, sigma_color, sigma_spatial, target_s):
     """Oracle (CPU restatement, row-parallel OpenMP) timed on a bounded strip of one image."""
     import numpy as np
     from oracle import c_oracle
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     h, w = joint0.shape[:2]
     r = c_oracle.jbf_radius(-1, sigma_spatial)
 
