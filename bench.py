@@ -135,6 +135,25 @@ def cpu_baseline(joint0, src0, sigma_color, sigma_spatial, target_s):
                       "bilateral, not OpenCV itself)" % (reps, hh, w, mp, t, cores)}
 
 
+def valu_roofline(n, h, w, radius, kernel_ms, taps_per_launch):
+    """Issue-floor time of the launch = column steps x 26 instructions x 2 cycles / (1024 SIMDs
+    x 2.4 GHz).  Column steps per wave follow the kernel's row walk: per tap row, groups of 4
+    columns covering -hw4 .. hw4+3 (hw = half-width of the disk on that row, hw4 = hw rounded up
+    to a multiple of 4)."""
+    steps_per_wave = 0
+    for i in range(-radius, radius + 1):
+        hw = int((radius * radius - i * i) ** 0.5)
+        hw4 = (hw + 3) & ~3
+        steps_per_wave += 4 * (hw4 // 2 + 1)
+    tiles = n * ((w + 63) // 64) * ((h + 63) // 64)
+    wave_steps = tiles * 16 * steps_per_wave          # 16 waves per 64x64 tile
+    floor_s = wave_steps * 26 * 2 / (1024 * 2.4e9)
+    return {"bound": "valu-issue", "instructions_per_column_step": 26,
+            "column_steps_per_launch": wave_steps, "floor_ms": floor_s * 1e3,
+            "frac": floor_s / (kernel_ms * 1e-3), "taps_per_s": taps_per_launch / (kernel_ms * 1e-3),
+            "lane_ops_per_tap": VALU_LANE_OPS_PER_S / (taps_per_launch / (kernel_ms * 1e-3))}
+
+
 def main():
     args = parse_args()
     import torch
@@ -229,11 +248,10 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "jbf_tile64_kernel<3,32,16>", "kernel_ms": kernel_ms,
                      "algorithmic_bytes_per_launch": launch_px * JBF_BYTES_PER_PX},
-        # the bound that actually limits an exact brute-force bilateral: VALU issue
-        "valu": {"taps_per_s": launch_px * taps / (kernel_ms * 1e-3),
-                 "lane_op_peak_per_s": VALU_LANE_OPS_PER_S,
-                 "lane_ops_per_tap_at_peak": VALU_LANE_OPS_PER_S
-                 / (launch_px * taps / (kernel_ms * 1e-3))},
+        # the bound that actually limits an exact brute-force bilateral: VALU issue.  The grey
+        # tap loop retires 26 VALU wave-instructions per 4-output column step; a gfx950 SIMD
+        # issues at most one per 2 cycles (tools/microbench/valu_rates2.hip), 1024 SIMDs, 2.4 GHz.
+        "valu": valu_roofline(n, h, w, radius, kernel_ms, launch_px * taps),
     }
     if rgb_ms:
         out["colour_src"] = {"value": launch_px / 1e6 / (rgb_ms * 1e-3), "unit": "MP/s",
