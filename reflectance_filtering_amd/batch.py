@@ -1,0 +1,171 @@
+#!/usr/bin/env python
+"""Batch front-end: the reference's two tools over many files, one process per GPU.
+
+The reference handles one image per invocation (/root/reference/filter_reflectance.py:76-96,
+/root/reference/decompose_with_trained_CNN.py:98-130).  Every image is independent, so a list of
+files shards embarrassingly: each rank (torchrun sets RANK/WORLD_SIZE/LOCAL_RANK) takes a
+contiguous slice of the sorted file list, groups its images by size, pushes each group through
+the device-resident batch operators and writes the same output files the single-image tools
+would write.  No collective is involved.
+
+    python -m reflectance_filtering_amd.batch filter --filter_type=bilateral --sigma_color=20 \
+        --sigma_spatial=22 --inputs 'out/*-r.png' --guidance 'photos/{stem}.png' --path_out out
+    python -m torch.distributed.run --nproc-per-node 8 -m reflectance_filtering_amd.batch \
+        decompose --inputs 'photos/*.png' --path_out out
+
+`--guidance` is a pattern evaluated per input: {path} {dir} {name} {stem} {ext}; `{stem}` of
+`x-r.png` is `x-r`, `{base}` strips a trailing `-r` as well, so `photos/{base}.png` pairs a CNN
+prediction with its photo.  Omit it to use each input as its own guidance (BF(CNN,CNN)).
+"""
+from __future__ import division, print_function
+
+import argparse
+import glob
+import os
+import sys
+
+import numpy as np
+
+from . import filter_reflectance as fr
+from . import image_utils as iu
+from . import sharding
+
+MAX_BATCH_BYTES = 2 << 30  # per group of equal-size images kept on the device at once
+
+
+def expand_inputs(patterns):
+    """Sorted, de-duplicated list of files matched by the patterns (a literal path matches itself)."""
+    files = []
+    for pat in patterns:
+        hits = sorted(glob.glob(pat))
+        files.extend(hits if hits else ([pat] if os.path.exists(pat) else []))
+    seen, out = set(), []
+    for f in files:
+        if f not in seen:
+            seen.add(f)
+            out.append(f)
+    return out
+
+
+def guidance_for(path, pattern):
+    """File name of the guidance image of `path` under `pattern` (None -> the input itself)."""
+    if not pattern:
+        return path
+    d, name = os.path.split(path)
+    stem, ext = os.path.splitext(name)
+    base = stem[:-2] if stem.endswith("-r") else stem
+    return pattern.format(path=path, dir=d, name=name, stem=stem, ext=ext, base=base)
+
+
+def my_slice(files, rank=None, world=None):
+    """The contiguous part of `files` this rank owns."""
+    if rank is None:
+        rank = int(os.environ.get("RANK", "0"))
+    if world is None:
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+    lo, hi = sharding.shard_range(len(files), world, rank)
+    return files[lo:hi]
+
+
+def group_by_shape(items, shape_of, max_bytes=MAX_BATCH_BYTES):
+    """Consecutive runs of `items` with equal shape, cut so that a run stays under max_bytes."""
+    groups, cur, cur_shape = [], [], None
+    for it in items:
+        shp = shape_of(it)
+        per = int(np.prod(shp))
+        if cur and (shp != cur_shape or (len(cur) + 1) * per > max_bytes):
+            groups.append(cur)
+            cur = []
+        cur.append(it)
+        cur_shape = shp
+    if cur:
+        groups.append(cur)
+    return groups
+
+
+def filter_files(filter_type, inputs, guidance_pattern, sigma_color, sigma_spatial, path_out,
+                 iterations=1, rank=None, world=None):
+    """filter_reflectance.read_filter_write over this rank's share of `inputs`; returns the
+    list of files written."""
+    import torch
+    fr._check_params(filter_type, sigma_color, sigma_spatial)
+    mine = my_slice(inputs, rank, world)
+    loaded = [(f, iu.imread(f), iu.imread(guidance_for(f, guidance_pattern))) for f in mine]
+    for f, img, gui in loaded:
+        if img.shape[:2] != gui.shape[:2]:
+            raise ValueError("input {} and its guidance differ in size".format(f))
+    written = []
+    for group in group_by_shape(loaded, lambda t: t[1].shape):
+        images = torch.from_numpy(np.stack([t[1] for t in group])).cuda()
+        joints = torch.from_numpy(np.stack([t[2] for t in group])).cuda()
+        out = fr.apply_filter_batch(filter_type, images, joints, sigma_color, sigma_spatial,
+                                    iterations=iterations).cpu().numpy()
+        for (f, _, _), res in zip(group, out):
+            name = f
+            for _ in range(iterations):  # the chained CLI runs append the suffix once per pass
+                name = fr.output_filename(name, path_out, filter_type, sigma_color, sigma_spatial)
+            iu.imwrite(name, res)
+            written.append(name)
+    return written
+
+
+def decompose_files(inputs, path_out, rank=None, world=None):
+    """decompose_image over this rank's share of `inputs` (the CNN runs batched on the device;
+    colourised outputs are formed on the host exactly as the single-image tool does)."""
+    import torch
+    from . import decompose_with_trained_CNN as dc
+    mine = my_slice(inputs, rank, world)
+    loaded = [(f, iu.imread(f)) for f in mine]
+    written = []
+    for group in group_by_shape(loaded, lambda t: t[1].shape):
+        images = torch.from_numpy(np.stack([t[1] for t in group])).cuda()
+        r, _ = dc.get_reflectance_batch(images)
+        r = r.cpu().numpy()
+        for (f, image), refl_gray in zip(group, r):
+            base = os.path.splitext(os.path.basename(f))[0]
+            iu.imwrite(os.path.join(path_out, base + "-r.png"), refl_gray)
+            reflectance, shading = iu.colorize(refl_gray, image)
+            iu.imwrite(os.path.join(path_out, base + "-r_colorized.png"), reflectance, sRGB=True)
+            iu.imwrite(os.path.join(path_out, base + "-s_colorized.png"), shading, sRGB=True)
+            written.append(os.path.join(path_out, base + "-r.png"))
+    return written
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(description="Batched, multi-GPU front-end of the two tools.")
+    sub = parser.add_subparsers(dest="command")
+    f = sub.add_parser("filter", help="filter_reflectance over many files")
+    f.add_argument("--inputs", nargs="+", required=True, help="files or glob patterns")
+    f.add_argument("--guidance", default=None, help="pattern for the guidance file (see module doc)")
+    f.add_argument("--path_out", required=True)
+    f.add_argument("--sigma_color", type=float, required=True)
+    f.add_argument("--sigma_spatial", type=float, required=True)
+    f.add_argument("--filter_type", required=True)
+    f.add_argument("--iterations", type=int, default=1)
+    d = sub.add_parser("decompose", help="decompose_with_trained_CNN over many files")
+    d.add_argument("--inputs", nargs="+", required=True)
+    d.add_argument("--path_out", required=True)
+    return parser
+
+
+def main(argv=None):
+    args = build_parser().parse_args(sys.argv[1:] if argv is None else argv)
+    if args.command is None:
+        build_parser().print_help()
+        return 0
+    import torch
+    local = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local % torch.cuda.device_count())
+    files = expand_inputs(args.inputs)
+    if args.command == "filter":
+        out = filter_files(args.filter_type, files, args.guidance, args.sigma_color,
+                           args.sigma_spatial, args.path_out, iterations=args.iterations)
+    else:
+        out = decompose_files(files, args.path_out)
+    print("rank {}: wrote {} file(s)".format(os.environ.get("RANK", "0"), len(out)))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -278,6 +278,44 @@ def test_grey_as_bgr_and_fused_chain(env):
                               co.joint_bilateral_filter(r3, r3.copy(), -1, 20, 22)[:, :, 0])
 
 
+def test_batch_front_end_matches_single_image_tools(env, tmp_path):
+    """The sharded multi-file front-end writes the same files as per-image CLI runs; two
+    'ranks' together cover every file exactly once."""
+    from tests import synth
+    rf, co, torch = env
+    from reflectance_filtering_amd import batch
+    iu = rf.image_utils
+    photos, preds, single, multi = (tmp_path / d for d in ("photos", "preds", "single", "multi"))
+    for d in (photos, preds, single, multi):
+        d.mkdir()
+    sizes = [(60, 81), (60, 81), (45, 70), (60, 81), (45, 70)]
+    for i, (h, w) in enumerate(sizes):
+        iu.imwrite(str(photos / ("im%d.png" % i)), synth.scene_u8(h, w, seed=i))
+    files = batch.expand_inputs([str(photos / "*.png")])
+    for rank in range(2):
+        batch.decompose_files(files, str(preds), rank=rank, world=2)
+    for f in files:
+        assert rf.decompose_with_trained_CNN.main(["--filename_in=" + f,
+                                                   "--path_out=" + str(single)]) == 0
+    for name in sorted(os.listdir(str(single))):
+        assert np.array_equal(iu.imread(str(preds / name)), iu.imread(str(single / name))), name
+    rfiles = batch.expand_inputs([str(preds / "*-r.png")])
+    assert len(rfiles) == 5
+    written = []
+    for rank in range(2):
+        written += batch.filter_files("guided", rfiles, str(photos / "{base}.png"), 3.0, 9.0,
+                                      str(multi), iterations=2, rank=rank, world=2)
+    assert len(written) == 5
+    for f in rfiles:
+        gui = batch.guidance_for(f, str(photos / "{base}.png"))
+        cur = f
+        for _ in range(2):
+            rf.read_filter_write("guided", cur, gui, 3.0, 9.0, str(single))
+            cur = rf.filter_reflectance.output_filename(cur, str(single), "guided", 3.0, 9.0)
+        twin = os.path.join(str(multi), os.path.basename(cur))
+        assert np.array_equal(iu.imread(twin), iu.imread(cur)), cur
+
+
 # ------------------------------------------------------------------------------ CLI chain
 def test_cli_chain_bf_cnn_cnn(env, tmp_path):
     """BASELINE config C3 in miniature: decompose CLI -> `-r.png` -> filter CLI with the

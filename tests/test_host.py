@@ -218,6 +218,26 @@ def test_decompose_image_outputs_match_reference(monkeypatch, tmp_path):
         assert np.array_equal(got, want), name
 
 
+def test_batch_front_end_host_logic(tmp_path):
+    from reflectance_filtering_amd import batch
+    for name in ("b-r.png", "a-r.png", "c.png"):
+        iu.imwrite(str(tmp_path / name), np.zeros((3, 4), np.uint8))
+    files = batch.expand_inputs([str(tmp_path / "*-r.png"), str(tmp_path / "c.png"),
+                                 str(tmp_path / "a-r.png"), str(tmp_path / "missing.png")])
+    assert [os.path.basename(f) for f in files] == ["a-r.png", "b-r.png", "c.png"]
+    assert batch.guidance_for("/x/y/118495-r.png", None) == "/x/y/118495-r.png"
+    assert batch.guidance_for("/x/y/118495-r.png", "/p/{base}{ext}") == "/p/118495.png"
+    assert batch.guidance_for("/x/y/img.png", "{dir}/flat/{stem}_flat{ext}") == "/x/y/flat/img_flat.png"
+    items = list("abcdefg")
+    parts = [batch.my_slice(items, r, 3) for r in range(3)]
+    assert sum(parts, []) == items and [len(p) for p in parts] == [3, 2, 2]
+    shapes = {"a": (4, 4, 3), "b": (4, 4, 3), "c": (5, 4, 3), "d": (5, 4, 3), "e": (5, 4, 3),
+              "f": (4, 4, 3), "g": (4, 4, 3)}
+    groups = batch.group_by_shape(items, lambda k: shapes[k], max_bytes=2 * 5 * 4 * 3)
+    assert groups == [["a", "b"], ["c", "d"], ["e"], ["f", "g"]]
+    assert batch.main([]) == 0
+
+
 def test_no_oracle_in_product():
     """The product package must never import or load the oracle (no CPU fallback)."""
     pkg = os.path.dirname(rf.__file__)
