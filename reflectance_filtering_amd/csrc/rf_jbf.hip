@@ -126,6 +126,13 @@ int get_tables(int radius, int joint_cn, double sigma_color, double sigma_space,
     RF_HIP_CHECK(hipMemcpy(t.d_dj, dj.data(), sizeof(int) * t.maxk, hipMemcpyHostToDevice));
     RF_HIP_CHECK(hipMemcpy(t.d_sw, sw.data(), sizeof(float) * t.maxk, hipMemcpyHostToDevice));
     RF_HIP_CHECK(hipMemcpy(t.d_hw, hw.data(), sizeof(int) * d, hipMemcpyHostToDevice));
+    // bounded cache: parameter sweeps must not accumulate device memory; evicting is safe only
+    // when no launch that uses the evicted tables is still queued, so sync this device first
+    if (g_tables.size() >= 64) {
+        RF_HIP_CHECK(hipDeviceSynchronize());
+        free_tables(g_tables.front());
+        g_tables.erase(g_tables.begin());
+    }
     g_tables.push_back(t);
     *out = t;
     return RF_OK;

@@ -11,6 +11,12 @@ _gf_workspaces = {}
 _cnn_consts = {}
 
 
+def release_workspaces():
+    """Drop the cached guided-filter scratch buffers and CNN constants (device memory)."""
+    _gf_workspaces.clear()
+    _cnn_consts.clear()
+
+
 def _chk_images(t, name, torch):
     if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.uint8
             and t.dim() == 4 and t.is_contiguous()):
