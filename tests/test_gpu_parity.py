@@ -154,6 +154,60 @@ def test_jbf_full_1080p_locality_and_batch(env):
     #  the contract and it is not flip-symmetric)
 
 
+def test_jbf_randomised_sweep(env):
+    """40 seeded random cases: sizes 1..170, both channel counts, every border type, radii on
+    both sides of the tile/pitch limits, batches of 1..3."""
+    from tests import synth
+    rf, co, torch = env
+    rng = np.random.default_rng(2024)
+    for case in range(40):
+        h, w = int(rng.integers(1, 171)), int(rng.integers(1, 171))
+        n = int(rng.integers(1, 4))
+        jcn, scn = int(rng.choice([1, 3])), int(rng.choice([1, 3]))
+        border = int(rng.integers(0, 5))
+        sc = float(rng.choice([3.0, 12.5, 20.0, 47.0, 130.0, 600.0]))
+        ss = float(rng.choice([0.4, 1.0, 3.7, 9.0, 15.0, 22.0, 24.5, 30.0, 36.0]))
+        d = int(rng.choice([-1, -1, -1, 3, 8, 21]))
+        joints = np.stack([synth.scene_u8(h, w, seed=1000 * case + i) for i in range(n)])
+        srcs = np.stack([synth.scene_u8(h, w, seed=1000 * case + 50 + i) if case % 3 else
+                         synth.reflectance_like_u8(h, w, seed=1000 * case + 50 + i)
+                         for i in range(n)])
+        joints = joints if jcn == 3 else joints[..., :1]
+        srcs = srcs if scn == 3 else srcs[..., 1:2]
+        got = rf.ops.joint_bilateral_u8(torch.from_numpy(np.ascontiguousarray(joints)).cuda(),
+                                        torch.from_numpy(np.ascontiguousarray(srcs)).cuda(), d, sc,
+                                        ss, border=border).cpu().numpy()
+        for i in range(n):
+            want = co.joint_bilateral_filter(joints[i], srcs[i], d, sc, ss, border=border)
+            assert np.array_equal(got[i], want.reshape(got[i].shape)), \
+                (case, h, w, n, jcn, scn, border, sc, ss, d)
+
+
+def test_gf_randomised_sweep(env):
+    from tests import synth
+    rf, co, torch = env
+    rng = np.random.default_rng(77)
+    for case in range(24):
+        h, w = int(rng.integers(1, 200)), int(rng.integers(1, 700))
+        n = int(rng.integers(1, 3))
+        scn = int(rng.choice([1, 3]))
+        r = int(rng.choice([0, 1, 2, 7, 19, 45, 52, 80, 120]))
+        eps = float(rng.choice([1e-4, 0.5, 3.0, 7.0, 400.0]))
+        iters = int(rng.choice([1, 1, 2]))
+        guides = np.stack([synth.flat_guide_u8(h, w, seed=case * 10 + i, cells=15) if case % 2
+                           else synth.scene_u8(h, w, seed=case * 10 + i) for i in range(n)])
+        srcs = np.stack([synth.reflectance_like_u8(h, w, seed=case * 10 + 5 + i) for i in range(n)])
+        srcs = srcs if scn == 3 else srcs[..., :1]
+        got = rf.ops.guided_filter_u8(torch.from_numpy(guides).cuda(),
+                                      torch.from_numpy(np.ascontiguousarray(srcs)).cuda(), r, eps,
+                                      iterations=iters).cpu().numpy()
+        for i in range(n):
+            want = srcs[i] if scn == 3 else srcs[i][:, :, 0]
+            for _ in range(iters):
+                want = co.guided_filter(guides[i], want, r, eps)
+            assert np.array_equal(got[i], want.reshape(got[i].shape)), (case, h, w, n, scn, r, eps)
+
+
 def test_empty_batch_aliasing_and_shutdown(env):
     from tests import synth
     rf, co, torch = env
