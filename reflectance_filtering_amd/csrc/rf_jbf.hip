@@ -7,10 +7,14 @@
 // separately rounded multiply then add -- the order of the 8u path of
 // opencv_contrib/modules/ximgproc/src/joint_bilateral_filter.cpp on a non-FMA build.
 //
-// Kernels:
-//   jbf_tiled2_kernel  one workgroup = 64 x TH output tile, software-pipelined LDS tap loop (see
-//                      the comment above jbf_tap_loop).
+// Kernels (selection in rf_jbf_u8 at the end of the file):
+//   jbf_tile64_kernel  default for radius <= 52: one workgroup = 64x64 output tile, 1024 threads
+//                      (4 waves/SIMD), LDS-staged texel tile, LUT at the end of LDS.
+//   jbf_tiled2_kernel  64 x TH tiles with 8-byte texels and a clamped/full LUT: used when the
+//                      LDS out-of-range probe fails, and by the tuning harness.
 //   jbf_generic_kernel untiled, any radius, global-memory gathers (fallback + cross-check).
+// Shared pieces: jbf_tap_loop (the software-pipelined tap loop, compiler-scheduled VALU) and
+// jbf_tap_loop_grey4 (its hand-interleaved form for grey tiles).
 #include <cmath>
 #include <mutex>
 #include <type_traits>
@@ -24,7 +28,7 @@ namespace {
 constexpr int kTileW = 64;
 constexpr int kPix = 4;        // outputs per lane (horizontal)
 constexpr int kMaxLds = 160 * 1024;
-constexpr int kTlw2 = 144;     // v2 tile row pitch in texels (covers radius <= 36)
+constexpr int kTlw2 = 144;     // tile row pitch in texels of jbf_tiled2_kernel (radius <= 36)
 
 typedef uint32_t uint2v __attribute__((ext_vector_type(2)));
 typedef float float4v __attribute__((ext_vector_type(4)));
@@ -41,7 +45,7 @@ struct JbfTables {
     int *d_dj = nullptr;        // [maxk]
     float *d_sw = nullptr;      // [maxk]
     int *d_hw = nullptr;        // [2r+1] half-width of the disk on tap row i
-    // v2: rows |i| = 0..r, each sw_len = 2*(r4+8) floats, centre at index r4+8, zeros outside
+    // weight rows |i| = 0..r, each sw_len = 2*(r4+8) floats, centre at index r4+8, zeros outside
     // the disk (the weights are symmetric in i and in j)
     int r4 = 0, sw_len = 0;
     float *d_swsym = nullptr;
@@ -305,9 +309,11 @@ __global__ __launch_bounds__(256) void jbf_generic_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// Tiled kernel, software-pipelined (v2).
+// Tiled kernels: the software-pipelined tap loop.
 //
-// Same tile idea as above, plus:
+// One workgroup stages its output tile plus halo into LDS (border handling happens there, so the
+// tap loop is branch-free); each lane owns 4 horizontally adjacent outputs and slides over the tap
+// row, so every texel read and its byte->float conversions feed 4 outputs.  In detail:
 //   * the tap row is walked in groups of 4 columns starting at a multiple of 4, so the texel
 //     address of column (group g, u) is  lane_base + u*(TLW/4) + g : one VALU add per group,
 //     immediates for the rest, and the spatial weights of the 4 columns x 4 outputs are a
@@ -319,8 +325,11 @@ __global__ __launch_bounds__(256) void jbf_generic_kernel(
 //   * LUTREP replicas of the colour LUT (32 = conflict-free, 16/8 trade conflicts for LDS).
 // Columns outside the disk carry zero weight: w = 0 adds +0.0 to non-negative sums, which is
 // bit-identical to skipping the tap.
-// LDS: [flag][lutrep lut_len*LUTREP f32][sw (r+1)*sw_len f32][tile (TH+2r) x TLW uint2]
-// Tile column X <-> image x = tile_x0 - r4 + X, stored at (X&3)*(TLW/4) + (X>>2).
+// jbf_tiled2_kernel LDS: [flag][lutrep lut_len*LUTREP f32][sw (r+1)*sw_len f32][tile (TH+2r) x TLW]
+// Tile column X <-> image x = tile_x0 - r4 + X, stored at (X&3)*(TLW/4) + (X>>2): the lane that
+// owns outputs 4t..4t+3 reads X = 4t + const, i.e. consecutive lanes read consecutive texels
+// (conflict-free) although each lane's own outputs are adjacent; TLW % 32 == 16 keeps the two
+// 16-lane rows of a 32-lane LDS group on disjoint banks.
 // ------------------------------------------------------------------------------------------
 // Block-wide AND of a predicate through one word of the caller's dynamic LDS (HIP's
 // __syncthreads_and brings 256 bytes of static LDS with it, which the kernels below cannot spare
