@@ -239,7 +239,6 @@ __global__ __launch_bounds__(64) void gf_rowsum_kernel(const float *__restrict__
     const float *S = planes + (size_t)plane * h * w;
     double *D = rowsums + (size_t)plane * h * w;
     const int ks = 2 * radius + 1;
-    const int my_row = min(row0 + lane, h - 1);
     const int sub = lane >> 5, col = lane & 31;  // loader role: 2 rows x 32 columns per instruction
 
     double s = 0.0;
@@ -284,7 +283,6 @@ __global__ __launch_bounds__(64) void gf_rowsum_kernel(const float *__restrict__
             }
         __syncthreads();
     }
-    (void)my_row;
 }
 
 // ------------------------------------------------------------------------------------------
