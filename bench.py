@@ -215,6 +215,19 @@ def main():
         rgb_ms = e0.elapsed_time(e1)
         del src_rgb
 
+    # BASELINE config C2: one 1080p image on one GPU (latency of a single launch)
+    single_ms = None
+    if rank == 0:
+        j1, s1, d1 = joint[:1].contiguous(), src[:1].contiguous(), dst[:1].contiguous()
+        rf.ops.joint_bilateral_u8(j1, s1, -1, args.sigma_color, args.sigma_spatial, out=d1)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            rf.ops.joint_bilateral_u8(j1, s1, -1, args.sigma_color, args.sigma_spatial, out=d1)
+        e1.record()
+        torch.cuda.synchronize()
+        single_ms = e0.elapsed_time(e1) / 10
+
     if rank != 0:
         return
     value = px_total / 1e6 / t_max
@@ -253,6 +266,9 @@ def main():
         # issues at most one per 2 cycles (tools/microbench/valu_rates2.hip), 1024 SIMDs, 2.4 GHz.
         "valu": valu_roofline(n, h, w, radius, kernel_ms, launch_px * taps),
     }
+    if single_ms:
+        out["single_image"] = {"ms": single_ms, "value": h * w / 1e6 / (single_ms * 1e-3),
+                               "unit": "MP/s", "note": "one %dx%d image per launch" % (w, h)}
     if rgb_ms:
         out["colour_src"] = {"value": launch_px / 1e6 / (rgb_ms * 1e-3), "unit": "MP/s",
                              "kernel_ms": rgb_ms, "note": "same launch, 3-channel colour src"}
