@@ -48,9 +48,13 @@ __host__ __device__ inline int border_interpolate(int p, int len, int border)
     return -1;
 }
 
-// saturate_cast<uchar>(float): cvRound (round-half-even) then clamp to 0..255.
+// saturate_cast<uchar>(float): cvRound (round-half-even) then clamp to 0..255.  cvRound is
+// cvtss2si on x86: NaN and anything outside the int range become INT_MIN, i.e. 0 after the clamp
+// (v_cvt_i32_f32 would saturate +inf to INT_MAX instead).
 __device__ inline uint8_t saturate_u8(float v)
 {
+    if (!(fabsf(v) < 2147483648.0f))
+        return 0;
     int iv = __float2int_rn(v);
     iv = iv < 0 ? 0 : (iv > 255 ? 255 : iv);
     return (uint8_t)iv;

@@ -246,6 +246,19 @@ def test_gf_matches_oracle_bitwise(env, h, w, r, eps):
     assert np.array_equal(got, want)
 
 
+def test_gf_degenerate_eps(env):
+    """eps = 0 on a flat guide: zero determinants, infinities and NaNs must round the way
+    OpenCV's cvRound/saturate_cast does on x86 (to 0), and tiny eps takes the det = 1 branch."""
+    from tests import synth
+    rf, co, torch = env
+    guide = np.full((40, 60, 3), 90, np.uint8)
+    guide[:, 30:] = (10, 200, 77)
+    src = synth.scene_u8(40, 60, seed=1)
+    for eps in (0.0, 1e-7, 5e-3):
+        got = rf.ximgproc.guidedFilter(guide, src, 4, eps)
+        assert np.array_equal(got, co.guided_filter(guide, src, 4, eps)), eps
+
+
 def test_gf_single_channel_src_and_iterations(env):
     from tests import synth
     rf, co, torch = env
