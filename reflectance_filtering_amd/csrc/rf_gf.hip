@@ -16,6 +16,13 @@
 //            sum down the image starting 2r rows above the first output row.  Both are
 //            reproduced as sequential chains (one lane per row / per column), exposed to the
 //            GPU as parallelism over rows x planes x images.  -> gf_rowsum_kernel, gf_colsum_apply_kernel
+//
+// Grey sources: the reference filters the CNN's grey `-r.png`, which imread turns into three
+// identical channels.  The src channels never mix, so identical channels give identical
+// outputs; gf_grey_probe_kernel marks such images (a device-side flag, no host round trip) and
+// they run the one-channel instantiation with the result byte written three times (1/3 of the
+// per-channel planes).  Every stage is launched in both instantiations; workgroups of the one
+// that does not apply to their image exit at once.
 #include "rf_common.hpp"
 
 namespace rf {
@@ -78,12 +85,53 @@ __device__ constexpr int sym(int i, int j)
     return i <= j ? (i * 3 - i * (i - 1) / 2 + (j - i)) : (j * 3 - j * (j - 1) / 2 + (i - j));
 }
 
-// grid: (strips, row segments, images).  ab: [img][SCN*4][h][w] float (g<3 alpha, g=3 beta)
+// colour[img] != 0  <=>  some pixel of the 3-channel image has unequal channels.
+// grid: (blocks per image, images); colour[] zeroed beforehand.
+__global__ __launch_bounds__(256) void gf_grey_probe_kernel(const uint8_t *__restrict__ src,
+                                                            int *__restrict__ colour, size_t npx)
+{
+    const uint8_t *simg = src + (size_t)blockIdx.y * npx * 3;
+    const size_t nquads = npx / 4;  // 4 pixels = 12 bytes = 3 dwords (image base is 4-aligned
+                                    // only when npx*3*img is; use byte-safe loads)
+    bool diff = false;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nquads;
+         q += (size_t)gridDim.x * blockDim.x) {
+        uint32_t d0, d1, d2;
+        __builtin_memcpy(&d0, simg + q * 12, 4);
+        __builtin_memcpy(&d1, simg + q * 12 + 4, 4);
+        __builtin_memcpy(&d2, simg + q * 12 + 8, 4);
+        // bytes: b0 g0 r0 b1 | g1 r1 b2 g2 | r2 b3 g3 r3 ; grey <=> every pixel's 3 bytes equal
+        const uint32_t p0 = d0 & 0xffffffu, p1 = (d0 >> 24) | ((d1 & 0xffffu) << 8);
+        const uint32_t p2 = (d1 >> 16) | ((d2 & 0xffu) << 16), p3 = d2 >> 8;
+        diff |= p0 != (p0 & 0xffu) * 0x010101u || p1 != (p1 & 0xffu) * 0x010101u ||
+                p2 != (p2 & 0xffu) * 0x010101u || p3 != (p3 & 0xffu) * 0x010101u;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(npx - nquads * 4)) {
+        const uint8_t *p = simg + (nquads * 4 + threadIdx.x) * 3;
+        diff |= p[0] != p[1] || p[1] != p[2];
+    }
+    if (diff)
+        colour[blockIdx.y] = 1;
+}
+
+// Does this workgroup's instantiation apply to image img?  (colour == nullptr: no choice to make)
 template <int SCN>
+__device__ inline bool wrong_variant(const int *__restrict__ colour, int img)
+{
+    return colour != nullptr && (colour[img] != 0) != (SCN == 3);
+}
+
+// grid: (strips, row segments, images).  ab: [img][SPX*4][h][w] float (g<3 alpha, g=3 beta).
+// SCN = src channels computed, SPX = src bytes per pixel (SCN, or 3 with SCN = 1 for a grey
+// 3-channel image whose first channel stands for all three).
+template <int SCN, int SPX>
 __global__ __launch_bounds__(kAThreads) void gf_stage1_kernel(
     const uint8_t *__restrict__ guide, const uint8_t *__restrict__ src, float *__restrict__ ab,
-    int h, int w, int radius, float eps_f, int eps_small, int seg_rows)
+    int h, int w, int radius, float eps_f, int eps_small, int seg_rows,
+    const int *__restrict__ colour)
 {
+    if (wrong_variant<SCN>(colour, blockIdx.z))
+        return;
     constexpr int NQ = Quant<SCN>::NQ;
     __shared__ uint32_t pfx[NQ][kACW + 1];
     __shared__ uint32_t wave_tot[NQ][kAWaves];
@@ -96,8 +144,8 @@ __global__ __launch_bounds__(kAThreads) void gf_stage1_kernel(
     const int ye = min(ys + seg_rows, h);
     const size_t npx = (size_t)h * w;
     const uint8_t *gimg = guide + (size_t)blockIdx.z * npx * 3;
-    const uint8_t *simg = src + (size_t)blockIdx.z * npx * SCN;
-    float *abimg = ab + (size_t)blockIdx.z * npx * (SCN * 4);
+    const uint8_t *simg = src + (size_t)blockIdx.z * npx * SPX;
+    float *abimg = ab + (size_t)blockIdx.z * npx * (SPX * 4);
     const int ks = 2 * radius + 1;
     const double scale = 1.0 / (double)(ks * ks);
 
@@ -119,7 +167,7 @@ __global__ __launch_bounds__(kAThreads) void gf_stage1_kernel(
         for (int k = 0; k < kACols; k++) {
             uint32_t v[NQ];
             const size_t pix = (size_t)gy * w + gx[k];
-            Quant<SCN>::eval(gimg + pix * 3, simg + pix * SCN, v);
+            Quant<SCN>::eval(gimg + pix * 3, simg + pix * SPX, v);
 #pragma unroll
             for (int q = 0; q < NQ; q++)
                 V[k][q] = add ? V[k][q] + v[q] : V[k][q] - v[q];
@@ -227,8 +275,15 @@ constexpr int kBChunk = 32;
 
 __global__ __launch_bounds__(64) void gf_rowsum_kernel(const float *__restrict__ planes,
                                                        double *__restrict__ rowsums, int h, int w,
-                                                       int radius, int row_blocks)
+                                                       int radius, int row_blocks, int np,
+                                                       const int *__restrict__ colour)
 {
+    {
+        // grey 3-channel images only carry the 4 planes of their first channel
+        const int pl = blockIdx.x / row_blocks;
+        if (colour != nullptr && pl % np >= 4 && colour[pl / np] == 0)
+            return;
+    }
     __shared__ float t_in[kBRows][kBChunk + 1];
     __shared__ float t_out_lo[kBRows][kBChunk + 1];  // leaving values
     __shared__ double t_d[kBRows][kBChunk + 1];
@@ -291,11 +346,13 @@ __global__ __launch_bounds__(64) void gf_rowsum_kernel(const float *__restrict__
 // top of the image; per output row the 4 means of a src channel meet in LDS and the beta
 // thread of that channel forms q = beta + a0*I0 + a1*I1 + a2*I2 and stores the byte.
 // ------------------------------------------------------------------------------------------
-template <int SCN>
+template <int SCN, int SPX>
 __global__ __launch_bounds__(64 * 4 * SCN) void gf_colsum_apply_kernel(
     const double *__restrict__ rowsums, const uint8_t *__restrict__ guide,
-    uint8_t *__restrict__ dst, int h, int w, int radius)
+    uint8_t *__restrict__ dst, int h, int w, int radius, const int *__restrict__ colour)
 {
+    if (wrong_variant<SCN>(colour, blockIdx.z))
+        return;
     constexpr int NP = 4 * SCN;
     constexpr int kDepth = 4;
     __shared__ float means[2][NP][64];
@@ -305,9 +362,9 @@ __global__ __launch_bounds__(64 * 4 * SCN) void gf_colsum_apply_kernel(
     const int x = blockIdx.x * 64 + lane;
     const int xc = min(x, w - 1);
     const size_t npx = (size_t)h * w;
-    const double *R = rowsums + ((size_t)blockIdx.z * NP + plane) * npx + xc;
+    const double *R = rowsums + ((size_t)blockIdx.z * (4 * SPX) + plane) * npx + xc;
     const uint8_t *gimg = guide + (size_t)blockIdx.z * npx * 3;
-    uint8_t *dimg = dst + (size_t)blockIdx.z * npx * SCN;
+    uint8_t *dimg = dst + (size_t)blockIdx.z * npx * SPX;
     const int ks = 2 * radius + 1;
     const double scale = 1.0 / (double)(ks * ks);
 
@@ -340,13 +397,24 @@ __global__ __launch_bounds__(64 * 4 * SCN) void gf_colsum_apply_kernel(
                 for (int g = 0; g < 3; g++)
                     q = __fadd_rn(q, __fmul_rn(means[y & 1][s * 4 + g][lane],
                                                (float)gimg[pix * 3 + g]));
-                dimg[pix * SCN + s] = saturate_u8(q);
+                const uint8_t o = saturate_u8(q);
+                if (SCN == SPX) {
+                    dimg[pix * SCN + s] = o;
+                } else {  // grey image: the one computed channel stands for all three
+                    dimg[pix * 3 + 0] = o;
+                    dimg[pix * 3 + 1] = o;
+                    dimg[pix * 3 + 2] = o;
+                }
             }
         }
     }
 }
 
 }  // namespace
+
+// per-image "has colour" flags at the head of the workspace
+size_t gf_header_bytes(int n) { return (((size_t)n * sizeof(int)) + 255) & ~(size_t)255; }
+
 }  // namespace rf
 
 extern "C" size_t rf_gf_workspace_bytes(int n, int h, int w, int guide_cn, int src_cn, int radius)
@@ -363,7 +431,7 @@ extern "C" size_t rf_gf_workspace_bytes(int n, int h, int w, int guide_cn, int s
         imgs = cap / per_img;
     if (imgs < 1)
         imgs = 1;
-    return imgs * per_img;
+    return rf::gf_header_bytes(n) + imgs * per_img;
 }
 
 extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, int n, int h,
@@ -392,11 +460,12 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
     const int np = 4 * src_cn;
     const size_t npx = (size_t)h * w;
     const size_t per_img = npx * np * (sizeof(float) + sizeof(double));
-    if (workspace_bytes < per_img)
-        return fail(RF_E_WORKSPACE, "rf_gf_u8: workspace %zu B < %zu B needed per image",
-                    workspace_bytes, per_img);
+    const size_t header = gf_header_bytes(n);
+    if (workspace_bytes < header + per_img)
+        return fail(RF_E_WORKSPACE, "rf_gf_u8: workspace %zu B < %zu B needed for one image",
+                    workspace_bytes, header + per_img);
     hipStream_t stream = (hipStream_t)stream_;
-    int chunk = (int)std::min<size_t>((size_t)n, workspace_bytes / per_img);
+    int chunk = (int)std::min<size_t>((size_t)n, (workspace_bytes - header) / per_img);
     if (chunk > 65535)
         chunk = 65535;
     const float eps_f = (float)eps;
@@ -404,9 +473,23 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
     const int out_w = kACW - 2 * radius;
     const int strips = ceil_div(w, out_w);
 
+    // 3-channel sources: find the images whose channels are identical (see the file header)
+    int *colour_all = nullptr;
+    if (src_cn == 3) {
+        colour_all = reinterpret_cast<int *>(workspace);
+        RF_HIP_CHECK(hipMemsetAsync(colour_all, 0, sizeof(int) * (size_t)n, stream));
+        const int pb = (int)std::min<size_t>(1024, (npx / 4 + 255) / 256 + 1);
+        for (int i0 = 0; i0 < n; i0 += 65535) {
+            const int m = std::min(65535, n - i0);
+            hipLaunchKernelGGL(gf_grey_probe_kernel, dim3(pb, m), dim3(256), 0, stream,
+                               src + (size_t)i0 * npx * 3, colour_all + i0, npx);
+        }
+    }
+
     for (int i0 = 0; i0 < n; i0 += chunk) {
         const int m = std::min(chunk, n - i0);
-        double *rows = reinterpret_cast<double *>(workspace);
+        const int *colour = colour_all ? colour_all + i0 : nullptr;
+        double *rows = reinterpret_cast<double *>(static_cast<char *>(workspace) + header);
         float *ab = reinterpret_cast<float *>(rows + (size_t)m * np * npx);
         const uint8_t *g0 = guide + (size_t)i0 * npx * 3;
         uint8_t *d0 = dst + (size_t)i0 * npx * src_cn;
@@ -419,22 +502,28 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
         for (int it = 0; it < iterations; it++) {
             const uint8_t *s0 = (it == 0 ? src : (const uint8_t *)dst) + (size_t)i0 * npx * src_cn;
             dim3 ga(strips, segs, m);
-            if (src_cn == 3)
-                hipLaunchKernelGGL(gf_stage1_kernel<3>, ga, dim3(kAThreads), 0, stream, g0, s0, ab,
-                                   h, w, radius, eps_f, eps_small, seg_rows);
-            else
-                hipLaunchKernelGGL(gf_stage1_kernel<1>, ga, dim3(kAThreads), 0, stream, g0, s0, ab,
-                                   h, w, radius, eps_f, eps_small, seg_rows);
+            if (src_cn == 3) {
+                hipLaunchKernelGGL((gf_stage1_kernel<3, 3>), ga, dim3(kAThreads), 0, stream, g0, s0,
+                                   ab, h, w, radius, eps_f, eps_small, seg_rows, colour);
+                hipLaunchKernelGGL((gf_stage1_kernel<1, 3>), ga, dim3(kAThreads), 0, stream, g0, s0,
+                                   ab, h, w, radius, eps_f, eps_small, seg_rows, colour);
+            } else {
+                hipLaunchKernelGGL((gf_stage1_kernel<1, 1>), ga, dim3(kAThreads), 0, stream, g0, s0,
+                                   ab, h, w, radius, eps_f, eps_small, seg_rows, colour);
+            }
             const int row_blocks = ceil_div(h, kBRows);
             hipLaunchKernelGGL(gf_rowsum_kernel, dim3((unsigned)(m * np * row_blocks)), dim3(64), 0,
-                               stream, ab, rows, h, w, radius, row_blocks);
+                               stream, ab, rows, h, w, radius, row_blocks, np, colour);
             dim3 gc(ceil_div(w, 64), 1, m);
-            if (src_cn == 3)
-                hipLaunchKernelGGL(gf_colsum_apply_kernel<3>, gc, dim3(64, 12), 0, stream, rows, g0,
-                                   d0, h, w, radius);
-            else
-                hipLaunchKernelGGL(gf_colsum_apply_kernel<1>, gc, dim3(64, 4), 0, stream, rows, g0,
-                                   d0, h, w, radius);
+            if (src_cn == 3) {
+                hipLaunchKernelGGL((gf_colsum_apply_kernel<3, 3>), gc, dim3(64, 12), 0, stream, rows,
+                                   g0, d0, h, w, radius, colour);
+                hipLaunchKernelGGL((gf_colsum_apply_kernel<1, 3>), gc, dim3(64, 4), 0, stream, rows,
+                                   g0, d0, h, w, radius, colour);
+            } else {
+                hipLaunchKernelGGL((gf_colsum_apply_kernel<1, 1>), gc, dim3(64, 4), 0, stream, rows,
+                                   g0, d0, h, w, radius, colour);
+            }
         }
     }
     RF_HIP_CHECK(hipGetLastError());

@@ -196,7 +196,10 @@ def test_gf_randomised_sweep(env):
         iters = int(rng.choice([1, 1, 2]))
         guides = np.stack([synth.flat_guide_u8(h, w, seed=case * 10 + i, cells=15) if case % 2
                            else synth.scene_u8(h, w, seed=case * 10 + i) for i in range(n)])
-        srcs = np.stack([synth.reflectance_like_u8(h, w, seed=case * 10 + 5 + i) for i in range(n)])
+        # grey (three equal channels: the one-channel fast path) and colour sources, mixed
+        srcs = np.stack([synth.reflectance_like_u8(h, w, seed=case * 10 + 5 + i)
+                         if (case + i) % 3 else synth.scene_u8(h, w, seed=case * 10 + 7 + i)
+                         for i in range(n)])
         srcs = srcs if scn == 3 else srcs[..., :1]
         got = rf.ops.guided_filter_u8(torch.from_numpy(guides).cuda(),
                                       torch.from_numpy(np.ascontiguousarray(srcs)).cuda(), r, eps,
@@ -259,6 +262,34 @@ def test_gf_degenerate_eps(env):
         assert np.array_equal(got, co.guided_filter(guide, src, 4, eps)), eps
 
 
+def test_gf_grey_and_colour_sources_in_one_batch(env):
+    """A 3-channel src with identical channels takes the one-channel path (result written three
+    times); one differing byte anywhere - first pixel, middle, the very last pixel of an image
+    whose pixel count is not a multiple of 4 - must send the image down the colour path."""
+    from tests import synth
+    rf, co, torch = env
+    h, w = 37, 41
+    guide = synth.scene_u8(h, w, seed=3)
+    grey = synth.reflectance_like_u8(h, w, seed=4)
+    srcs = [grey.copy() for _ in range(6)]
+    srcs[1][0, 0, 1] ^= 0x40
+    srcs[2][h // 2, w // 3, 2] ^= 0x01
+    srcs[3][h - 1, w - 1, 0] ^= 0x80
+    srcs[4][h - 1, w - 2, 2] ^= 0x10
+    srcs[5] = synth.scene_u8(h, w, seed=5)
+    batch = np.stack(srcs)
+    guides = np.stack([guide] * len(srcs))
+    for iters in (1, 3):
+        got = rf.ops.guided_filter_u8(torch.from_numpy(guides).cuda(),
+                                      torch.from_numpy(batch).cuda(), 9, 3.0,
+                                      iterations=iters).cpu().numpy()
+        for i, s in enumerate(srcs):
+            want = s
+            for _ in range(iters):
+                want = co.guided_filter(guide, want, 9, 3.0)
+            assert np.array_equal(got[i], want), (iters, i)
+
+
 def test_gf_single_channel_src_and_iterations(env):
     from tests import synth
     rf, co, torch = env
@@ -289,9 +320,9 @@ def test_gf_1080p_against_oracle(env):
     from tests import synth
     rf, co, torch = env
     guide = synth.flat_guide_u8(1080, 1920, seed=50, cells=60)
-    src = synth.reflectance_like_u8(1080, 1920, seed=51)
-    got = rf.ximgproc.guidedFilter(guide, src, 45, 3.0)
-    assert np.array_equal(got, co.guided_filter(guide, src, 45, 3.0))
+    for src in (synth.reflectance_like_u8(1080, 1920, seed=51), synth.scene_u8(1080, 1920, seed=52)):
+        got = rf.ximgproc.guidedFilter(guide, src, 45, 3.0)
+        assert np.array_equal(got, co.guided_filter(guide, src, 45, 3.0))
 
 
 # ------------------------------------------------------------------------------ CNN

@@ -44,11 +44,14 @@ def main():
     scene, grey = bench.synth_batch(torch, n, h, w, 5000, dev)
     flat = (scene // 32) * 32 + 16  # posterised scene = piecewise-constant "flat" guidance
     dst = torch.empty_like(grey)
-    for iters in (1, 3):
-        ms = timed(torch, lambda: rf.ops.guided_filter_u8(flat, grey, 45, 3.0, iterations=iters,
-                                                          out=dst))
-        out["gf_4k_x%d" % iters] = {"ms": ms, "mp_per_s": n * h * w / 1e6 / (ms * 1e-3),
-                                    "batch": n}
+    # grey src (the CNN map the reference filters; three equal channels -> one-channel path)
+    # and a colour src (all three channels computed)
+    for tag, src in (("", grey), ("_colour_src", scene)):
+        for iters in (1, 3):
+            ms = timed(torch, lambda: rf.ops.guided_filter_u8(flat, src, 45, 3.0,
+                                                              iterations=iters, out=dst))
+            out["gf_4k_x%d%s" % (iters, tag)] = {"ms": ms, "batch": n,
+                                                 "mp_per_s": n * h * w / 1e6 / (ms * 1e-3)}
     del scene, grey, flat, dst
     torch.cuda.empty_cache()
 
