@@ -47,6 +47,8 @@ extern "C" {
                                  grey PNG (colour distance 3*|d|); with a 1-channel src the 1-channel result
                                  equals every channel of the 3-channel one */
 #define RF_JBF_TUNE_SHIFT 8    /* bits 8..11: kernel-variant override used by the benchmarks; 0 = auto */
+/* bits 12..14 are benchmark / test aids that never change results except 0x1000: 0x1000 stage the
+   tile and stop (timing only), 0x2000 compiler-scheduled tap loop, 0x4000 64x64 tiles only */
 
 int rf_version(void);
 const char *rf_last_error(void);

@@ -804,14 +804,20 @@ __global__ __launch_bounds__(16 * TH) void jbf_tiled2_kernel(
 // ------------------------------------------------------------------------------------------
 constexpr int kT64Lds = 163840;
 
-template <int SCN, int GREP, int CREP, int TLW>
+// TH = tile rows: 64 (64x64 tile), or 32 / 16 for the 32x128 and 16x256 strips that cover the
+// last h % 64 rows (same 1024 lanes, same tap loops, less padding; 3-channel sources only have
+// the 32-row strip, whose colour tile still fits the LDS in one pass).
+template <int SCN, int GREP, int CREP, int TLW, int TH = 64>
 __global__ __launch_bounds__(1024) void jbf_tile64_kernel(
     const uint8_t *__restrict__ joint, const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
     int h, int w, int jcn, int radius, int border, const float *__restrict__ lut, int nz,
     const int *__restrict__ hwtab, const float *__restrict__ swsym, int sw_len, int tiles_x,
-    int tiles_per_img, int flags, int crows)
+    int tiles_per_img, int flags, int crows, int y_base)
 {
     constexpr int NT = 1024;
+    constexpr int QW = NT / TH;   // lanes (4-pixel quads) per tile row
+    constexpr int TW = 4 * QW;    // tile width
+    static_assert(TH == 64 || TH == 32 || (TH == 16 && SCN == 1), "tile shapes");
     static_assert(TLW % 32 == 16, "row pitch keeps 16-lane rows on disjoint banks");
     constexpr int Q4 = TLW / 4;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -827,12 +833,12 @@ __global__ __launch_bounds__(1024) void jbf_tile64_kernel(
     const int tile_id = xcd_contiguous_tile((int)blockIdx.x, (int)gridDim.x);
     const int img_idx = tile_id / tiles_per_img;
     const int t_in_img = tile_id - img_idx * tiles_per_img;
-    const int tile_y0 = (t_in_img / tiles_x) * 64;
-    const int tile_x0 = (t_in_img % tiles_x) * kTileW;
+    const int tile_y0 = y_base + (t_in_img / tiles_x) * TH;
+    const int tile_x0 = (t_in_img % tiles_x) * TW;
     const size_t img = (size_t)img_idx * h * w;
     const int r4 = (radius + 3) & ~3;
-    const int tx = tid & 15;
-    const int ty = tid >> 4;
+    const int tx = tid % QW;
+    const int ty = tid / QW;
 
     // ---- weight table, grey LUT (optimistic), grey-packed tile ----
     for (int i = tid; i < (radius + 1) * sw_len; i += NT)
@@ -842,7 +848,7 @@ __global__ __launch_bounds__(1024) void jbf_tile64_kernel(
         lut_g[i] = lut[i / GREP];
     uint32_t *tile4 = reinterpret_cast<uint32_t *>(tile_raw);
     int grey = 1;
-    const int tlh = 64 + 2 * radius;
+    const int tlh = TH + 2 * radius;
     // one work item = 4 consecutive tile columns (4k..4k+3) of one tile row
     for (int item = tid; item < tlh * Q4; item += NT) {
         const int ry = item / Q4, k = item - ry * Q4;
@@ -887,7 +893,7 @@ __global__ __launch_bounds__(1024) void jbf_tile64_kernel(
     }
 
     if constexpr (SCN == 3) {
-        if (crows == 64) {
+        if (crows == TH) {
             // ---- colour src, one pass: the grey-packed plane already holds {B,G,R joint, B src};
             //      a second plane of 2-byte texels adds {G src, R src}: 6 bytes per texel, all
             //      1024 threads stay busy (4 waves/SIMD) ----
@@ -926,6 +932,8 @@ __global__ __launch_bounds__(1024) void jbf_tile64_kernel(
             store_quad<3, 3>(dst, img, tile_y0 + ty, tile_x0 + 4 * tx, h, w, sum, wsum, flags);
             return;
         }
+        if constexpr (TH != 64)
+            return;  // strips are only launched when the one-pass colour tile fits
         // ---- colour src: 64/crows passes of crows rows with 8-byte texels (crows = 32 when
         //      the LDS allows it, i.e. two halves run by threads 0..511) ----
         uint2 *tile8 = reinterpret_cast<uint2 *>(tile_raw);
@@ -1061,19 +1069,21 @@ int lds_oob_reads_zero(int dev, bool *ok)
 // LDS needed by jbf_tile64_kernel for grey / colour tiles with the given LUT replication.
 // Rows per colour pass that fit (64 = one pass with 6-byte texels; 32, 16, 8 = passes with
 // 8-byte texels), or 0.
-int tile64_fits(const JbfTables &t, int nz, int grep, int crep, int scn, int tlw)
+int tile64_fits(const JbfTables &t, int nz, int grep, int crep, int scn, int tlw, int th = 64)
 {
-    if (2 * t.r4 + kTileW + 8 > tlw)
+    if (2 * t.r4 + 4 * (1024 / th) + 8 > tlw)
         return 0;
     const size_t sw_bytes = 16 + (((size_t)(t.radius + 1) * t.sw_len * 4 + 15) & ~(size_t)15);
-    const size_t grey = sw_bytes + (size_t)tlw * (64 + 2 * t.radius) * 4 + (size_t)nz * grep * 4;
+    const size_t grey = sw_bytes + (size_t)tlw * (th + 2 * t.radius) * 4 + (size_t)nz * grep * 4;
     if (grey > (size_t)kT64Lds)
         return 0;
     if (scn == 1)
         return 32;
-    // colour tiles in one pass: a 4-byte and a 2-byte plane of the full 64-row tile
-    if (sw_bytes + (size_t)tlw * (64 + 2 * t.radius) * 6 + (size_t)nz * crep * 4 <= (size_t)kT64Lds)
-        return 64;
+    // colour tiles in one pass: a 4-byte and a 2-byte plane of the full tile
+    if (sw_bytes + (size_t)tlw * (th + 2 * t.radius) * 6 + (size_t)nz * crep * 4 <= (size_t)kT64Lds)
+        return th;
+    if (th != 64)
+        return 0;
     for (int crows = 32; crows >= 8; crows >>= 1) {
         const size_t col =
             sw_bytes + (size_t)tlw * (crows + 2 * t.radius) * 8 + (size_t)nz * crep * 4;
@@ -1083,22 +1093,64 @@ int tile64_fits(const JbfTables &t, int nz, int grep, int crep, int scn, int tlw
     return 0;
 }
 
-template <int SCN, int GREP, int CREP, int TLW>
+// Rows [y_base, y_base + rows) of every image, in tiles of TH rows.
+template <int SCN, int GREP, int CREP, int TLW, int TH = 64>
 int launch_tile64(const JbfTables &t, int nz, int crows, const uint8_t *joint, const uint8_t *src,
                   uint8_t *dst, int n, int h, int w, int jcn, int border, int flags,
-                  hipStream_t stream)
+                  hipStream_t stream, int y_base = 0, int rows = -1)
 {
-    const int tiles_x = ceil_div(w, kTileW), tiles_y = ceil_div(h, 64);
+    if (rows < 0)
+        rows = h;
+    const int tiles_x = ceil_div(w, 4 * (1024 / TH)), tiles_y = ceil_div(rows, TH);
     const long long blocks = (long long)tiles_x * tiles_y * n;
     if (blocks > 0x7fffffffLL)
         return fail(RF_E_UNSUPPORTED, "rf_jbf_u8: batch too large for one launch");
-    auto kern = jbf_tile64_kernel<SCN, GREP, CREP, TLW>;
+    auto kern = jbf_tile64_kernel<SCN, GREP, CREP, TLW, TH>;
     RF_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      kT64Lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(1024), kT64Lds, stream, joint, src, dst,
                        h, w, jcn, t.radius, border, t.d_lut, nz, t.d_hw, t.d_swsym, t.sw_len,
-                       tiles_x, tiles_x * tiles_y, flags, crows);
+                       tiles_x, tiles_x * tiles_y, flags, crows, y_base);
     return RF_OK;
+}
+
+// Radius <= 36: 64x64 tiles down to the last h % 64 rows, which go to one 32x128 and/or (single-
+// channel sources) one 16x256 strip of tiles when that takes fewer workgroups than another row
+// of 64x64 tiles (every workgroup costs the same 1024 lanes x all taps).
+template <int SCN, int GREP, int CREP>
+int launch_tile64_rows(const JbfTables &t, int nz, int crows, const uint8_t *joint,
+                       const uint8_t *src, uint8_t *dst, int n, int h, int w, int jcn, int border,
+                       int flags, hipStream_t stream)
+{
+    const int rem = h & 63;
+    const bool ok32 = tile64_fits(t, nz, GREP, CREP, SCN, 208, 32) > 0;
+    const bool ok16 = SCN == 1 && tile64_fits(t, nz, GREP, CREP, SCN, 336, 16) > 0;
+    int s32 = 0, s16 = 0;  // rows given to each strip
+    if (rem > 0 && rem <= 16 && ok16)
+        s16 = rem;
+    else if (rem > 0 && rem <= 32 && ok32)
+        s32 = rem;
+    else if (rem > 32 && rem <= 48 && ok32 && ok16)
+        s32 = 32, s16 = rem - 32;
+    const int strip_blocks = (s32 ? ceil_div(w, 128) : 0) + (s16 ? ceil_div(w, 256) : 0);
+    if ((s32 || s16) && strip_blocks >= ceil_div(w, 64))
+        s32 = s16 = 0;
+    if (flags & 0x4000)  // benchmark / test aid: 64x64 tiles only
+        s32 = s16 = 0;
+    const int rows_main = h - s32 - s16;
+    int rc = RF_OK;
+    if (rows_main > 0)
+        rc = launch_tile64<SCN, GREP, CREP, 144>(t, nz, crows, joint, src, dst, n, h, w, jcn,
+                                                 border, flags, stream, 0, rows_main);
+    if (rc == RF_OK && s32)
+        rc = launch_tile64<SCN, GREP, CREP, 208, 32>(t, nz, 32, joint, src, dst, n, h, w, jcn,
+                                                     border, flags, stream, rows_main, s32);
+    if constexpr (SCN == 1) {
+        if (rc == RF_OK && s16)
+            rc = launch_tile64<1, GREP, CREP, 336, 16>(t, nz, 32, joint, src, dst, n, h, w, jcn,
+                                                       border, flags, stream, rows_main + s32, s16);
+    }
+    return rc;
 }
 
 }  // namespace
@@ -1179,10 +1231,18 @@ extern "C" int rf_jbf_u8(const uint8_t *joint, const uint8_t *src, uint8_t *dst,
 #define RF_T64(G_, C_, W_)                                                                        \
     if (!done && tile64_fits(t, nz, G_, C_, src_cn, W_) > 0) {                                    \
         const int crows_ = tile64_fits(t, nz, G_, C_, src_cn, W_);                                \
-        rc = src_cn == 3 ? launch_tile64<3, G_, C_, W_>(t, nz, crows_, joint, src, dst, n, h, w,  \
-                                                        jcn_kernel, border, flags, stream)        \
-                         : launch_tile64<1, G_, C_, W_>(t, nz, crows_, joint, src, dst, n, h, w,  \
-                                                        jcn_kernel, border, flags, stream);       \
+        if (W_ == 144)                                                                            \
+            rc = src_cn == 3 ? launch_tile64_rows<3, G_, C_>(t, nz, crows_, joint, src, dst, n,   \
+                                                             h, w, jcn_kernel, border, flags,     \
+                                                             stream)                              \
+                             : launch_tile64_rows<1, G_, C_>(t, nz, crows_, joint, src, dst, n,   \
+                                                             h, w, jcn_kernel, border, flags,     \
+                                                             stream);                             \
+        else                                                                                      \
+            rc = src_cn == 3 ? launch_tile64<3, G_, C_, W_>(t, nz, crows_, joint, src, dst, n, h, \
+                                                            w, jcn_kernel, border, flags, stream) \
+                             : launch_tile64<1, G_, C_, W_>(t, nz, crows_, joint, src, dst, n, h, \
+                                                            w, jcn_kernel, border, flags, stream);\
         if (rc != RF_OK)                                                                          \
             return rc;                                                                            \
         done = true;                                                                              \

@@ -183,6 +183,33 @@ def test_jbf_randomised_sweep(env):
                 (case, h, w, n, jcn, scn, border, sc, ss, d)
 
 
+def test_jbf_strip_tiles(env):
+    """Single-channel sources finish the last h % 64 rows with 32x128 / 16x256 tiles; every
+    remainder class must match the oracle and the 64x64-only launch (flag 0x4000)."""
+    from tests import synth
+    rf, co, torch = env
+    w = 300
+    for h in (7, 16, 17, 32, 33, 48, 49, 64, 64 + 13, 128 + 32, 64 + 40, 333):
+        joint = synth.scene_u8(h, w, seed=h)
+        grey = synth.reflectance_like_u8(h, w, seed=h + 1)[:, :, :1].copy()
+        for jt, as_bgr in ((joint, False), (grey, True)):   # colour joint; grey joint as BGR
+            jd, sd = _dev(torch, jt, grey)
+            got = rf.ops.joint_bilateral_u8(jd, sd, -1, 20.0, 22.0, grey_as_bgr=as_bgr)
+            j3 = jt if jt.shape[2] == 3 else np.repeat(jt, 3, axis=2)
+            want = co.joint_bilateral_filter(j3, grey, -1, 20.0, 22.0)
+            assert np.array_equal(got.cpu().numpy()[0], want), (h, as_bgr)
+            only64 = rf.ops.joint_bilateral_u8(jd, sd, -1, 20.0, 22.0, grey_as_bgr=as_bgr,
+                                               flags=0x4000)
+            assert torch.equal(only64, got), (h, as_bgr)
+        # 3-channel sources (32-row strips only): a colour one and a grey one
+        for src3 in (synth.scene_u8(h, w, seed=h + 2), np.repeat(grey, 3, axis=2)):
+            jd, sd = _dev(torch, joint, src3)
+            got = rf.ops.joint_bilateral_u8(jd, sd, -1, 20.0, 22.0)
+            assert np.array_equal(got.cpu().numpy()[0],
+                                  co.joint_bilateral_filter(joint, src3, -1, 20.0, 22.0)), h
+            assert torch.equal(rf.ops.joint_bilateral_u8(jd, sd, -1, 20.0, 22.0, flags=0x4000), got)
+
+
 def test_gf_randomised_sweep(env):
     from tests import synth
     rf, co, torch = env
