@@ -812,13 +812,16 @@ __global__ __launch_bounds__(1024) void jbf_tile64_kernel(
     const uint8_t *__restrict__ joint, const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
     int h, int w, int jcn, int radius, int border, const float *__restrict__ lut, int nz,
     const int *__restrict__ hwtab, const float *__restrict__ swsym, int sw_len, int tiles_x,
-    int tiles_per_img, int flags, int crows, int y_base)
+    int tiles_per_img, int flags, int crows, int y_base, int x_base)
 {
     constexpr int NT = 1024;
     constexpr int QW = NT / TH;   // lanes (4-pixel quads) per tile row
     constexpr int TW = 4 * QW;    // tile width
-    static_assert(TH == 64 || TH == 32 || (TH == 16 && SCN == 1), "tile shapes");
-    static_assert(TLW % 32 == 16, "row pitch keeps 16-lane rows on disjoint banks");
+    static_assert(TH == 64 || TH == 32 || ((TH == 16 || TH == 128) && SCN == 1), "tile shapes");
+    // a half-wave covers 32/QW tile rows of QW consecutive words each: the pitch must spread
+    // those rows over disjoint banks
+    static_assert(QW >= 32 || (QW == 16 && TLW % 32 == 16) || (QW == 8 && TLW % 32 == 8),
+                  "row pitch keeps the rows of a half-wave on disjoint banks");
     constexpr int Q4 = TLW / 4;
     extern __shared__ __align__(16) unsigned char smem[];
     volatile int *flag_word = reinterpret_cast<volatile int *>(smem);
@@ -834,7 +837,7 @@ __global__ __launch_bounds__(1024) void jbf_tile64_kernel(
     const int img_idx = tile_id / tiles_per_img;
     const int t_in_img = tile_id - img_idx * tiles_per_img;
     const int tile_y0 = y_base + (t_in_img / tiles_x) * TH;
-    const int tile_x0 = (t_in_img % tiles_x) * TW;
+    const int tile_x0 = x_base + (t_in_img % tiles_x) * TW;
     const size_t img = (size_t)img_idx * h * w;
     const int r4 = (radius + 3) & ~3;
     const int tx = tid % QW;
@@ -1097,11 +1100,13 @@ int tile64_fits(const JbfTables &t, int nz, int grep, int crep, int scn, int tlw
 template <int SCN, int GREP, int CREP, int TLW, int TH = 64>
 int launch_tile64(const JbfTables &t, int nz, int crows, const uint8_t *joint, const uint8_t *src,
                   uint8_t *dst, int n, int h, int w, int jcn, int border, int flags,
-                  hipStream_t stream, int y_base = 0, int rows = -1)
+                  hipStream_t stream, int y_base = 0, int rows = -1, int x_base = 0, int cols = -1)
 {
     if (rows < 0)
         rows = h;
-    const int tiles_x = ceil_div(w, 4 * (1024 / TH)), tiles_y = ceil_div(rows, TH);
+    if (cols < 0)
+        cols = w;
+    const int tiles_x = ceil_div(cols, 4 * (1024 / TH)), tiles_y = ceil_div(rows, TH);
     const long long blocks = (long long)tiles_x * tiles_y * n;
     if (blocks > 0x7fffffffLL)
         return fail(RF_E_UNSUPPORTED, "rf_jbf_u8: batch too large for one launch");
@@ -1110,18 +1115,29 @@ int launch_tile64(const JbfTables &t, int nz, int crows, const uint8_t *joint, c
                                      kT64Lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(1024), kT64Lds, stream, joint, src, dst,
                        h, w, jcn, t.radius, border, t.d_lut, nz, t.d_hw, t.d_swsym, t.sw_len,
-                       tiles_x, tiles_x * tiles_y, flags, crows, y_base);
+                       tiles_x, tiles_x * tiles_y, flags, crows, y_base, x_base);
     return RF_OK;
 }
 
-// Radius <= 36: 64x64 tiles down to the last h % 64 rows, which go to one 32x128 and/or (single-
-// channel sources) one 16x256 strip of tiles when that takes fewer workgroups than another row
-// of 64x64 tiles (every workgroup costs the same 1024 lanes x all taps).
+// Radius <= 36: 64x64 tiles, except that the last h % 64 rows go to one 32x128 and/or one 16x256
+// strip of tiles, and the last w % 64 columns to a column of 128x32 tiles, whenever that takes
+// fewer workgroups than another row / column of 64x64 tiles (every workgroup costs the same
+// 1024 lanes x all taps).  3-channel sources only have the 32x128 strip, whose colour tile still
+// fits the LDS in one pass.  Strips may overlap at the bottom right corner: both write the same
+// bytes.
 template <int SCN, int GREP, int CREP>
 int launch_tile64_rows(const JbfTables &t, int nz, int crows, const uint8_t *joint,
                        const uint8_t *src, uint8_t *dst, int n, int h, int w, int jcn, int border,
                        int flags, hipStream_t stream)
 {
+    const bool only64 = (flags & 0x4000) != 0;  // benchmark / test aid: 64x64 tiles only
+    // ---- right strip (single-channel sources)
+    int sx = 0;
+    if (SCN == 1 && !only64 && (w & 63) > 0 && (w & 63) <= 32 &&
+        tile64_fits(t, nz, GREP, CREP, SCN, 136, 128) > 0 && ceil_div(h, 128) < ceil_div(h, 64))
+        sx = w & 63;
+    const int cols_main = w - sx;
+    // ---- bottom strips
     const int rem = h & 63;
     const bool ok32 = tile64_fits(t, nz, GREP, CREP, SCN, 208, 32) > 0;
     const bool ok16 = SCN == 1 && tile64_fits(t, nz, GREP, CREP, SCN, 336, 16) > 0;
@@ -1132,23 +1148,27 @@ int launch_tile64_rows(const JbfTables &t, int nz, int crows, const uint8_t *joi
         s32 = rem;
     else if (rem > 32 && rem <= 48 && ok32 && ok16)
         s32 = 32, s16 = rem - 32;
-    const int strip_blocks = (s32 ? ceil_div(w, 128) : 0) + (s16 ? ceil_div(w, 256) : 0);
-    if ((s32 || s16) && strip_blocks >= ceil_div(w, 64))
-        s32 = s16 = 0;
-    if (flags & 0x4000)  // benchmark / test aid: 64x64 tiles only
+    const int strip_blocks =
+        (s32 ? ceil_div(cols_main, 128) : 0) + (s16 ? ceil_div(cols_main, 256) : 0);
+    if (only64 || cols_main == 0 || ((s32 || s16) && strip_blocks >= ceil_div(cols_main, 64)))
         s32 = s16 = 0;
     const int rows_main = h - s32 - s16;
     int rc = RF_OK;
-    if (rows_main > 0)
+    if (rows_main > 0 && cols_main > 0)
         rc = launch_tile64<SCN, GREP, CREP, 144>(t, nz, crows, joint, src, dst, n, h, w, jcn,
-                                                 border, flags, stream, 0, rows_main);
+                                                 border, flags, stream, 0, rows_main, 0, cols_main);
     if (rc == RF_OK && s32)
         rc = launch_tile64<SCN, GREP, CREP, 208, 32>(t, nz, 32, joint, src, dst, n, h, w, jcn,
-                                                     border, flags, stream, rows_main, s32);
+                                                     border, flags, stream, rows_main, s32, 0,
+                                                     cols_main);
     if constexpr (SCN == 1) {
         if (rc == RF_OK && s16)
             rc = launch_tile64<1, GREP, CREP, 336, 16>(t, nz, 32, joint, src, dst, n, h, w, jcn,
-                                                       border, flags, stream, rows_main + s32, s16);
+                                                       border, flags, stream, rows_main + s32, s16,
+                                                       0, cols_main);
+        if (rc == RF_OK && sx)
+            rc = launch_tile64<1, GREP, CREP, 136, 128>(t, nz, 32, joint, src, dst, n, h, w, jcn,
+                                                        border, flags, stream, 0, h, cols_main, sx);
     }
     return rc;
 }

@@ -201,6 +201,8 @@ def test_jbf_strip_tiles(env):
             only64 = rf.ops.joint_bilateral_u8(jd, sd, -1, 20.0, 22.0, grey_as_bgr=as_bgr,
                                                flags=0x4000)
             assert torch.equal(only64, got), (h, as_bgr)
+        if h > 64:
+            continue  # (the 3-channel cases below on the small heights only, for time)
         # 3-channel sources (32-row strips only): a colour one and a grey one
         for src3 in (synth.scene_u8(h, w, seed=h + 2), np.repeat(grey, 3, axis=2)):
             jd, sd = _dev(torch, joint, src3)
@@ -208,6 +210,25 @@ def test_jbf_strip_tiles(env):
             assert np.array_equal(got.cpu().numpy()[0],
                                   co.joint_bilateral_filter(joint, src3, -1, 20.0, 22.0)), h
             assert torch.equal(rf.ops.joint_bilateral_u8(jd, sd, -1, 20.0, 22.0, flags=0x4000), got)
+
+
+@pytest.mark.parametrize("h,w", [(500, 333), (130, 96), (200, 20), (129, 65), (333, 500),
+                                 (77, 77), (140, 33)])
+def test_jbf_right_and_bottom_strips(env, h, w):
+    """Portrait / odd sizes: the last w % 64 columns of single-channel sources run as 128x32
+    tiles, possibly together with bottom strips; bit-equal to the oracle and to 64x64 tiles."""
+    from tests import synth
+    rf, co, torch = env
+    joint = synth.scene_u8(h, w, seed=h * 7 + w)
+    grey = synth.reflectance_like_u8(h, w, seed=h + w)[:, :, :1].copy()
+    for jt, as_bgr in ((joint, False), (grey, True)):
+        jd, sd = _dev(torch, jt, grey)
+        got = rf.ops.joint_bilateral_u8(jd, sd, -1, 20.0, 22.0, grey_as_bgr=as_bgr)
+        j3 = jt if jt.shape[2] == 3 else np.repeat(jt, 3, axis=2)
+        assert np.array_equal(got.cpu().numpy()[0],
+                              co.joint_bilateral_filter(j3, grey, -1, 20.0, 22.0)), as_bgr
+        assert torch.equal(rf.ops.joint_bilateral_u8(jd, sd, -1, 20.0, 22.0, grey_as_bgr=as_bgr,
+                                                     flags=0x4000), got)
 
 
 def test_gf_randomised_sweep(env):

@@ -60,21 +60,27 @@ def main():
     ms = timed(torch, lambda: rf.ops.guided_filter_u8(scene, grey, 52, 7.0))
     out["gf_256_single"] = {"ms": ms}
 
-    # C3: CNN + BF(CNN,CNN) at 500x333
-    n, h, w = args.cnn_batch, 333, 500
-    scene, _ = bench.synth_batch(torch, n, h, w, 5002, dev)
-    ms_cnn = timed(torch, lambda: rf.get_reflectance_batch(scene))
-    out["cnn_iiw"] = {"ms": ms_cnn, "mp_per_s": n * h * w / 1e6 / (ms_cnn * 1e-3), "batch": n}
-    _, r8 = rf.get_reflectance_batch(scene)
-    r3 = r8.unsqueeze(-1).expand(-1, -1, -1, 3).contiguous()
-    r3b = r3.clone()
-    o = torch.empty_like(r3)
-    ms_bf = timed(torch, lambda: rf.ops.joint_bilateral_u8(r3b, r3, -1, 20, 22, out=o))
-    out["bf_cnn_cnn_iiw"] = {"ms": ms_bf, "mp_per_s": n * h * w / 1e6 / (ms_bf * 1e-3), "batch": n}
+    # C3: CNN + BF(CNN,CNN) at IIW size, landscape 500x333 and portrait 333x500
+    for tag, (h, w) in (("iiw", (333, 500)), ("iiw_portrait", (500, 333))):
+        n = args.cnn_batch
+        scene, _ = bench.synth_batch(torch, n, h, w, 5002, dev)
+        mp = n * h * w / 1e6
+        if tag == "iiw":
+            ms_cnn = timed(torch, lambda: rf.get_reflectance_batch(scene))
+            out["cnn_iiw"] = {"ms": ms_cnn, "mp_per_s": mp / (ms_cnn * 1e-3), "batch": n}
+            _, r8 = rf.get_reflectance_batch(scene)
+            r3 = r8.unsqueeze(-1).expand(-1, -1, -1, 3).contiguous()
+            r3b, dst = r3.clone(), torch.empty_like(r3)
+            ms_bf = timed(torch, lambda: rf.ops.joint_bilateral_u8(r3b, r3, -1, 20.0, 22.0,
+                                                                   out=dst))
+            out["bf_cnn_cnn_iiw"] = {"ms": ms_bf, "mp_per_s": mp / (ms_bf * 1e-3), "batch": n}
+            del r3, r3b, dst
+        # fused chain: u8 BGR -> CNN -> trunc*255 -> BF(CNN,CNN) -> u8, no host hand-off
+        ms = timed(torch, lambda: rf.decompose_and_filter_batch(scene))
+        out["c3_chain_" + tag] = {"ms": ms, "mp_per_s": mp / (ms * 1e-3), "batch": n,
+                                  "ms_per_image": ms / n}
+        del scene
 
-    ms = timed(torch, lambda: rf.decompose_and_filter_batch(scene))
-    out["c3_chain_iiw"] = {"ms": ms, "mp_per_s": n * h * w / 1e6 / (ms * 1e-3), "batch": n,
-                           "ms_per_image": ms / n}
     print(json.dumps(out, indent=1))
 
 
