@@ -105,6 +105,29 @@ int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, int n, int 
 int rf_cnn_reflectance_u8(const uint8_t *bgr, float *r_out, uint8_t *r_u8_out, int n, int h, int w,
                           const float *weights, const float *srgb_lut, void *stream);
 
+/*
+ * Colourised reflectance and shading PNG bytes of decompose_image.
+ * Replaces the host numpy chain  iu.colorize(reflectance_gray, image)  +  iu.imwrite(..., sRGB=True)
+ * of both results (/root/reference/decompose_with_trained_CNN.py:121-128,
+ * /root/reference/image_utils.py:42-49, 60-92) for a batch that is already on the device:
+ *   shading = mean_c(bgr) / r ; reflectance = bgr / max(shading, 1e-3)          (float64)
+ *   each: if max > 1: clip(x / percentile(x, 99.9, 'lower'), 0, 1); rgb_to_srgb; trunc(x * 255)
+ *   bgr          n*h*w*3 uint8 device        r   n*h*w float32 device (the CNN output)
+ *   refl_out     n*h*w*3 uint8 device or NULL (bytes of `<base>-r_colorized.png`, BGR order)
+ *   shading_out  n*h*w   uint8 device or NULL (bytes of `<base>-s_colorized.png`)
+ *   k_refl, k_shading  0-based rank of the 99.9-percentile ('lower') among the 3*h*w resp. h*w
+ *                values of one image, computed by the caller with numpy's own index rule
+ *   srgb_steps   255 float64 on the device: srgb_steps[k-1] = smallest x in (0.0031308, 1] with
+ *                trunc(((1.055*x)^(1/2.4) - 0.055) * 255) >= k under the HOST's pow (+inf if none);
+ *                this makes the bytes exact for the libm the reference would have used
+ *   workspace    device scratch, rf_colorize_workspace_bytes(n) bytes
+ */
+size_t rf_colorize_workspace_bytes(int n);
+int rf_colorize_srgb_u8(const uint8_t *bgr, const float *r, uint8_t *refl_out, uint8_t *shading_out,
+                        int n, int h, int w, unsigned long long k_refl, unsigned long long k_shading,
+                        const double *srgb_steps, void *workspace, size_t workspace_bytes,
+                        void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -110,8 +110,9 @@ def filter_files(filter_type, inputs, guidance_pattern, sigma_color, sigma_spati
 
 
 def decompose_files(inputs, path_out, rank=None, world=None):
-    """decompose_image over this rank's share of `inputs` (the CNN runs batched on the device;
-    colourised outputs are formed on the host exactly as the single-image tool does)."""
+    """decompose_image over this rank's share of `inputs`: CNN, colourisation, percentile
+    normalisation and the sRGB byte conversion all run batched on the device; the host only
+    decodes and encodes the image files."""
     import torch
     from . import decompose_with_trained_CNN as dc
     mine = my_slice(inputs, rank, world)
@@ -119,14 +120,13 @@ def decompose_files(inputs, path_out, rank=None, world=None):
     written = []
     for group in group_by_shape(loaded, lambda t: t[1].shape):
         images = torch.from_numpy(np.stack([t[1] for t in group])).cuda()
-        r, _ = dc.get_reflectance_batch(images)
-        r = r.cpu().numpy()
-        for (f, image), refl_gray in zip(group, r):
+        _, r8, refl, shad = dc.decompose_batch(images)
+        r8, refl, shad = r8.cpu().numpy(), refl.cpu().numpy(), shad.cpu().numpy()
+        for i, (f, _) in enumerate(group):
             base = os.path.splitext(os.path.basename(f))[0]
-            iu.imwrite(os.path.join(path_out, base + "-r.png"), refl_gray)
-            reflectance, shading = iu.colorize(refl_gray, image)
-            iu.imwrite(os.path.join(path_out, base + "-r_colorized.png"), reflectance, sRGB=True)
-            iu.imwrite(os.path.join(path_out, base + "-s_colorized.png"), shading, sRGB=True)
+            iu.imwrite(os.path.join(path_out, base + "-r.png"), r8[i])
+            iu.imwrite(os.path.join(path_out, base + "-r_colorized.png"), refl[i])
+            iu.imwrite(os.path.join(path_out, base + "-s_colorized.png"), shad[i])
             written.append(os.path.join(path_out, base + "-r.png"))
     return written
 

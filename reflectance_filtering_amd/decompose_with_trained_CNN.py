@@ -109,6 +109,16 @@ def decompose_and_filter_batch(images, sigma_color=20.0, sigma_spatial=22.0, wei
     return r8, out.squeeze(-1)
 
 
+def decompose_batch(images, weights=None):
+    """Everything decompose_image writes, for a device-resident batch: CUDA uint8 BGR
+    [N,H,W,3] -> (r float32 [N,H,W], r_u8 [N,H,W] = `-r.png`, reflectance bytes [N,H,W,3] =
+    `-r_colorized.png`, shading bytes [N,H,W] = `-s_colorized.png`), no host arithmetic
+    (/root/reference/decompose_with_trained_CNN.py:113-128)."""
+    r, r8 = ops.cnn_reflectance_u8(images, weights=weights)
+    refl, shad = ops.colorize_srgb_u8(images, r)
+    return r, r8, refl, shad
+
+
 def decompose_image(filename_in, path_out, caffemodel=None):
     """Predict reflectance intensity for one image file and write `<base>-r.png`,
     `<base>-r_colorized.png`, `<base>-s_colorized.png`

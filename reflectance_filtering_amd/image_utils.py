@@ -61,6 +61,53 @@ def srgb_byte_lut():
     return srgb_to_rgb(np.arange(256, dtype=np.float64) / 255.0).astype(np.float32)
 
 
+_steps_cache = None
+
+
+def srgb_write_steps():
+    """float64[255] for the device colourise path: entry k-1 is the smallest x in (0.0031308, 1]
+    for which imwrite(..., sRGB=True) stores a byte >= k, i.e.
+    ((rgb_to_srgb(x)) * 255).astype(uint8) >= k, evaluated with THIS host's numpy (np.power is
+    libm's pow, which a GPU cannot reproduce bit for bit; a table of the <= 255 steps of the
+    monotone byte curve can).  +inf where no x <= 1 reaches the byte (rgb_to_srgb(1) = 0.9676)."""
+    global _steps_cache
+    if _steps_cache is not None:
+        return _steps_cache
+
+    def byte_of(x):
+        return (rgb_to_srgb(x) * 255).astype(np.uint8).astype(np.int64)
+
+    ks = np.arange(1, 256, dtype=np.int64)
+    first = np.nextafter(np.float64(0.0031308), np.float64(1.0))
+    lo = np.full(255, first.view(np.int64), dtype=np.int64)       # candidates as bit patterns
+    hi = np.full(255, np.float64(1.0).view(np.int64), dtype=np.int64)
+    reach = byte_of(np.full(255, 1.0)) >= ks                       # byte(1.0) >= k ?
+    # invariant: byte(hi) >= k (where reachable); find the smallest such bit pattern in [lo, hi]
+    while np.any(lo < hi):
+        mid = lo + (hi - lo) // 2
+        ok = byte_of(mid.view(np.float64)) >= ks
+        hi = np.where(ok, mid, hi)
+        lo = np.where(ok, lo, np.minimum(mid + 1, hi))
+    steps = hi.view(np.float64).copy()
+    steps[~reach] = np.inf
+    _steps_cache = steps
+    return steps
+
+
+_rank_cache = {}
+
+
+def percentile_rank(count):
+    """0-based index, into the sorted values, of np.percentile(x, 99.9, 'lower') for x.size ==
+    count - obtained from numpy itself so that the installed version's index arithmetic is the
+    one that counts (/root/reference/image_utils.py:90)."""
+    count = int(count)
+    if count not in _rank_cache:
+        _rank_cache[count] = int(np.percentile(np.arange(count, dtype=np.int64), 99.9,
+                                               method="lower"))
+    return _rank_cache[count]
+
+
 def normalize(img):
     """Scale to 0..1: identity if max <= 1, else divide by the 99.9th percentile ('lower') and
     clip.  Mirrors /root/reference/image_utils.py:84-92 (works on a copy)."""

@@ -15,6 +15,7 @@ def release_workspaces():
     """Drop the cached guided-filter scratch buffers and CNN constants (device memory)."""
     _gf_workspaces.clear()
     _cnn_consts.clear()
+    _steps_dev.clear()
 
 
 def _chk_images(t, name, torch):
@@ -113,3 +114,42 @@ def cnn_reflectance_u8(bgr, weights=None, want_float=True, want_u8=True):
                                    lut.data_ptr(), _ffi.current_stream_ptr(torch))
     _ffi.check(rc, "rf_cnn_reflectance_u8")
     return r, r8
+
+
+_steps_dev = {}
+
+
+def colorize_srgb_u8(images, r, want_reflectance=True, want_shading=True):
+    """Device form of iu.colorize(r, image) followed by iu.imwrite(..., sRGB=True) of both
+    results (/root/reference/decompose_with_trained_CNN.py:121-128): returns the uint8 bytes of
+    `<base>-r_colorized.png` [N,H,W,3] (BGR) and `<base>-s_colorized.png` [N,H,W].
+    images: CUDA uint8 [N,H,W,3]; r: CUDA float32 [N,H,W] (the CNN's reflectance intensity)."""
+    from . import image_utils as iu
+    torch = _ffi.require_gpu()
+    lib = _ffi.load_library()
+    _chk_images(images, "images", torch)
+    if images.shape[3] != 3:
+        raise ValueError("images must have 3 channels")
+    if (not torch.is_tensor(r) or not r.is_cuda or r.dtype != torch.float32
+            or tuple(r.shape) != tuple(images.shape[:3]) or not r.is_contiguous()):
+        raise ValueError("r must be a contiguous CUDA float32 tensor [N,H,W] matching images")
+    n, h, w, _ = images.shape
+    dev = images.device
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    steps = _steps_dev.get(key)
+    if steps is None:
+        steps = torch.from_numpy(iu.srgb_write_steps()).to(dev)
+        _steps_dev[key] = steps
+    refl = torch.empty((n, h, w, 3), dtype=torch.uint8, device=dev) if want_reflectance else None
+    shad = torch.empty((n, h, w), dtype=torch.uint8, device=dev) if want_shading else None
+    if n == 0 or (refl is None and shad is None):
+        return refl, shad
+    ws = torch.empty(lib.rf_colorize_workspace_bytes(n), dtype=torch.uint8, device=dev)
+    rc = lib.rf_colorize_srgb_u8(images.data_ptr(), r.data_ptr(),
+                                 refl.data_ptr() if refl is not None else None,
+                                 shad.data_ptr() if shad is not None else None, n, h, w,
+                                 iu.percentile_rank(3 * h * w), iu.percentile_rank(h * w),
+                                 steps.data_ptr(), ws.data_ptr(), ws.numel(),
+                                 _ffi.current_stream_ptr(torch))
+    _ffi.check(rc, "rf_colorize_srgb_u8")
+    return refl, shad

@@ -267,6 +267,34 @@ save("decompose_outputs.npz", scene=scene, r=np.array(r_scene),
      r_colorized_png=files_out["/out/dir/scene.01-r_colorized.png"],
      s_colorized_png=files_out["/out/dir/scene.01-s_colorized.png"])
 
+# F9: colorize + imwrite(sRGB=True) on larger inputs (the device colourise path is pinned on these):
+# a natural-looking image, a dark one (max <= 1: no normalisation), one with black pixels and a
+# saturated region, a tiny one.  Inputs and the bytes the reference hands to cv2.imwrite.
+rng9 = np.random.default_rng(909)
+f9 = {}
+for tag, (hh, ww) in {"natural": (48, 64), "dark": (20, 24), "holes": (33, 31), "tiny": (1, 3)}.items():
+    yy, xx = np.mgrid[0:hh, 0:ww]
+    base = 110 + 70 * np.sin(yy / 7.0) * np.cos(xx / 5.0)
+    img = np.clip(base[:, :, None] + rng9.normal(0, 25, (hh, ww, 3)), 0, 255).astype(np.uint8)
+    r = (0.1 + 0.85 * rng9.random((hh, ww))).astype(np.float32)
+    if tag == "dark":
+        img = (img // 128).astype(np.uint8)          # values 0/1
+        r = np.full((hh, ww), 0.999, np.float32)     # refl = r * img / mean <= ~3; shading <= ~1
+        img[:, :] = img[:, :, :1]                    # grey: reflectance = r <= 1, shading = 1/r > 1
+    if tag == "holes":
+        img[5:12, 3:20] = 0
+        img[20:30, 10:25] = 255
+        r[0, 0] = 1e-4
+    files_out.clear()
+    refl9, shad9 = ref_iu.colorize(r, img)
+    ref_iu.imwrite("/out/f9-r_colorized.png", refl9, sRGB=True)
+    ref_iu.imwrite("/out/f9-s_colorized.png", shad9, sRGB=True)
+    f9[tag + "_image"] = img
+    f9[tag + "_r"] = r
+    f9[tag + "_refl_png"] = files_out["/out/f9-r_colorized.png"]
+    f9[tag + "_shading_png"] = files_out["/out/f9-s_colorized.png"]
+save("colorize_write.npz", **f9)
+
 with open(os.path.join(HERE, "cli_plumbing.json"), "w") as fh:
     json.dump(plumbing, fh, indent=1, sort_keys=True, default=str)
 print("wrote cli_plumbing.json")

@@ -55,7 +55,13 @@ def test_argument_validation_needs_no_gpu(built):
     assert lib.rf_gf_u8(p, q, o, 1, 4, 4, 3, 3, 500, 1.0, 1, p, 1 << 20, None) == _ffi.RF_E_UNSUPPORTED
     assert lib.rf_gf_u8(p, q, o, 1, 64, 64, 3, 3, 2, 1.0, 1, p, 16, None) == _ffi.RF_E_WORKSPACE
     assert lib.rf_cnn_reflectance_u8(p, None, None, 1, 4, 4, p, p, None) == _ffi.RF_E_BADARG
-    assert lib.rf_gf_workspace_bytes(1, 100, 200, 3, 3, 45) == 100 * 200 * 12 * 12
+    # 256-byte header (per-image grey flags) + 12 float and 12 double planes
+    assert lib.rf_gf_workspace_bytes(1, 100, 200, 3, 3, 45) == 256 + 100 * 200 * 12 * 12
+    assert lib.rf_colorize_workspace_bytes(0) == 0 and lib.rf_colorize_workspace_bytes(3) > 0
+    assert lib.rf_colorize_srgb_u8(p, q, o, None, 1, 4, 4, 0, 0, None, p, 1 << 20, None) == _ffi.RF_E_BADARG
+    assert lib.rf_colorize_srgb_u8(p, q, o, None, 1, 4, 4, 48, 0, p, p, 1 << 20, None) == _ffi.RF_E_BADARG
+    assert b"rank" in lib.rf_last_error()
+    assert lib.rf_colorize_srgb_u8(p, q, o, None, 1, 4, 4, 47, 15, p, p, 8, None) == _ffi.RF_E_WORKSPACE
     assert lib.rf_gf_workspace_bytes(1, 100, 200, 3, 2, 45) == 0
     with pytest.raises(ValueError):
         _ffi.check(_ffi.RF_E_BADARG, "x")

@@ -490,3 +490,51 @@ def test_cli_chain_bf_cnn_cnn(env, tmp_path):
                                        "--guidance_in=" + src, "--path_out=" + str(tmp_path)]) == 0
     out = iu.imread(str(tmp_path / "img-r_guided_c3.0s45.0.png"))
     assert np.array_equal(out, co.guided_filter(scene, r_png, 45, 3.0))
+
+
+# ------------------------------------------------------------------------------ colourise
+def test_colorize_matches_reference_bytes(env):
+    """Device colorize + sRGB write path against bytes captured from the reference's own
+    colorize/imwrite (tests/golden/colorize_write.npz, decompose_outputs.npz)."""
+    rf, co, torch = env
+    d = np.load(os.path.join(G, "colorize_write.npz"))
+    cases = [(d[t + "_image"], d[t + "_r"], d[t + "_refl_png"], d[t + "_shading_png"])
+             for t in ("natural", "dark", "holes", "tiny")]
+    g = np.load(os.path.join(G, "decompose_outputs.npz"))
+    cases.append((g["scene"], g["r"], g["r_colorized_png"], g["s_colorized_png"]))
+    for img, r, want_refl, want_shad in cases:
+        refl, shad = rf.ops.colorize_srgb_u8(torch.from_numpy(img[None]).cuda(),
+                                             torch.from_numpy(r[None]).cuda())
+        assert np.array_equal(refl.cpu().numpy()[0], want_refl)
+        assert np.array_equal(shad.cpu().numpy()[0], want_shad)
+
+
+def test_colorize_batch_against_oracle(env):
+    """Batches (per-image percentiles), odd sizes, real CNN output as r, only one output."""
+    from oracle import colorize_numpy as oc
+    from tests import synth
+    rf, co, torch = env
+    rng = np.random.default_rng(12)
+    for h, w, n in ((333, 500, 3), (7, 5, 4), (64, 257, 2), (1, 1, 2)):
+        imgs = np.stack([synth.scene_u8(h, w, seed=h + i) for i in range(n)])
+        imgs[0, : h // 2] //= 4                      # a dark half: different percentile per image
+        if n > 2:
+            imgs[2] = 0                              # black image: nothing to normalise
+        dev = torch.from_numpy(imgs).cuda()
+        r, _ = rf.get_reflectance_batch(dev)
+        refl, shad = rf.ops.colorize_srgb_u8(dev, r)
+        r_host = r.cpu().numpy()
+        for i in range(n):
+            want_refl, want_shad = oc.colorize_srgb_u8(imgs[i], r_host[i])
+            assert np.array_equal(refl[i].cpu().numpy(), want_refl), (h, w, i)
+            assert np.array_equal(shad[i].cpu().numpy(), want_shad), (h, w, i)
+        only_r, none = rf.ops.colorize_srgb_u8(dev, r, want_shading=False)
+        assert none is None and torch.equal(only_r, refl)
+    # random r (not the CNN's) incl. tiny values
+    imgs = rng.integers(0, 256, (2, 40, 30, 3), dtype=np.uint8)
+    r = (10.0 ** rng.uniform(-4, 0, (2, 40, 30))).astype(np.float32)
+    refl, shad = rf.ops.colorize_srgb_u8(torch.from_numpy(imgs).cuda(), torch.from_numpy(r).cuda())
+    for i in range(2):
+        want_refl, want_shad = oc.colorize_srgb_u8(imgs[i], r[i])
+        assert np.array_equal(refl[i].cpu().numpy(), want_refl)
+        assert np.array_equal(shad[i].cpu().numpy(), want_shad)
