@@ -75,6 +75,11 @@ def main():
                                                                    out=dst))
             out["bf_cnn_cnn_iiw"] = {"ms": ms_bf, "mp_per_s": mp / (ms_bf * 1e-3), "batch": n}
             del r3, r3b, dst
+        if tag == "iiw":
+            r, _ = rf.get_reflectance_batch(scene)
+            ms_col = timed(torch, lambda: rf.ops.colorize_srgb_u8(scene, r))
+            out["colorize_iiw"] = {"ms": ms_col, "mp_per_s": mp / (ms_col * 1e-3), "batch": n}
+            del r
         # fused chain: u8 BGR -> CNN -> trunc*255 -> BF(CNN,CNN) -> u8, no host hand-off
         ms = timed(torch, lambda: rf.decompose_and_filter_batch(scene))
         out["c3_chain_" + tag] = {"ms": ms, "mp_per_s": mp / (ms * 1e-3), "batch": n,
