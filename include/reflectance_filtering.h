@@ -128,6 +128,21 @@ int rf_colorize_srgb_u8(const uint8_t *bgr, const float *r, uint8_t *refl_out, u
                         const double *srgb_steps, void *workspace, size_t workspace_bytes,
                         void *stream);
 
+/*
+ * WHDR (weighted human disagreement rate, Bell et al. 2014) of a batch of reflectance predictions.
+ * Replaces the per-comparison Python loop  whdr(reflectance, comparisons, delta)  of
+ * /root/reference/training/layers/whdr_layer.py:253-287 (lightness: :180-196).
+ *   refl     n*c*h*w float32 device, planar [n][c][h][w], c in {1,3}
+ *   points   total*5 int32 device: x1, y1, x2, y2 (pixels, inside the image), darker (0 'E', 1, 2)
+ *   weights  total float64 device: darker_score of each comparison
+ *   offsets  n+1 int32 device: comparisons of image i are [offsets[i], offsets[i+1])
+ *   out      n float64 device: error_sum / weight_sum (0 for an image without comparisons)
+ * Lightness and ratios are float32 and compared with (float)(1 + delta); the two sums are float64,
+ * accumulated in comparison order.
+ */
+int rf_whdr_f32(const float *refl, int n, int c, int h, int w, const int *points,
+                const double *weights, const int *offsets, double delta, double *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,6 +16,7 @@ from . import ops  # noqa: F401
 from . import ximgproc  # noqa: F401
 from . import filter_reflectance  # noqa: F401
 from . import decompose_with_trained_CNN  # noqa: F401
+from . import whdr  # noqa: F401
 from .filter_reflectance import apply_filter, apply_filter_batch, read_filter_write  # noqa: F401
 from .decompose_with_trained_CNN import (  # noqa: F401
     decompose_and_filter_batch, decompose_batch, decompose_image, get_reflectance_batch,

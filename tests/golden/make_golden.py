@@ -134,6 +134,7 @@ class FakeNet(object):
 caffe = types.ModuleType("caffe")
 caffe.TEST = "TEST"
 caffe.Net = FakeNet
+caffe.Layer = object   # base class of the reference's python layers (training/layers/*.py)
 sys.modules["caffe"] = caffe
 
 sys.path.insert(0, REF)
@@ -294,6 +295,36 @@ for tag, (hh, ww) in {"natural": (48, 64), "dark": (20, 24), "holes": (33, 31), 
     f9[tag + "_refl_png"] = files_out["/out/f9-r_colorized.png"]
     f9[tag + "_shading_png"] = files_out["/out/f9-s_colorized.png"]
 save("colorize_write.npz", **f9)
+
+# F10: WHDR (training/layers/whdr_layer.py): pixel-coordinate extraction and the weighted
+# disagreement rate on seeded predictions, 1 and 3 channels, incl. an image without comparisons
+# and points whose lightness is floored at eps.
+sys.path.insert(0, os.path.join(REF, "training", "layers"))
+import whdr_layer as ref_whdr  # noqa: E402
+rng10 = np.random.default_rng(1010)
+f10 = {}
+for tag, (cc, hh, ww, ncomp) in {"grey": (1, 40, 56, 300), "colour": (3, 33, 47, 257),
+                                 "none": (1, 8, 8, 0), "single": (3, 5, 4, 1)}.items():
+    refl = (0.02 + 0.98 * rng10.random((cc, hh, ww))).astype(np.float32)
+    refl[:, 0, 0] = 0.0                      # lightness floored at eps
+    refl[:, 1, 1] = refl[:, 2, 2] * np.float32(1.1)   # ratios right at 1 + delta
+    blob = np.full((ncomp + 1, 6), np.nan)
+    blob[:ncomp, 0:4] = rng10.random((ncomp, 4)) * 0.999
+    if ncomp > 4:
+        blob[0, 0:4] = [0.0, 0.0, 0.5, 0.5]
+        blob[1, 0:4] = [1.5 / ww, 1.5 / hh, 2.5 / ww, 2.5 / hh]
+        blob[2, 0:4] = [2.5 / ww, 2.5 / hh, 1.5 / ww, 1.5 / hh]
+    blob[:ncomp, 4] = rng10.integers(0, 3, ncomp)
+    blob[:ncomp, 5] = rng10.random(ncomp) * 2.0
+    blob[ncomp, 0] = ncomp
+    blob[ncomp, 1] = 12345.0
+    blob[ncomp, 2] = 0
+    px = ref_whdr._extract_valid_comparisons_with_actual_size(blob, hh, ww)
+    f10[tag + "_refl"] = refl
+    f10[tag + "_comparisons"] = blob[:ncomp].copy()
+    f10[tag + "_pixels"] = px
+    f10[tag + "_whdr"] = np.array([ref_whdr.whdr(refl, px, d) for d in (0.1, 0.0, 0.25)])
+save("whdr.npz", **f10)
 
 with open(os.path.join(HERE, "cli_plumbing.json"), "w") as fh:
     json.dump(plumbing, fh, indent=1, sort_keys=True, default=str)

@@ -1,0 +1,79 @@
+"""WHDR evaluator: the host mirror against values produced by the reference's
+own whdr_layer.whdr (tests/golden/whdr.npz), the IIW JSON reader, and - on a GPU - the batch
+kernel against both."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from reflectance_filtering_amd import whdr as W
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TAGS = ("grey", "colour", "none", "single")
+DELTAS = (0.1, 0.0, 0.25)
+
+
+def test_host_whdr_matches_reference_values():
+    d = np.load(os.path.join(G, "whdr.npz"))
+    for tag in TAGS:
+        refl, comp = d[tag + "_refl"], d[tag + "_comparisons"]
+        px = W.to_pixels(comp, refl.shape[1], refl.shape[2])
+        assert np.array_equal(px, d[tag + "_pixels"]), tag
+        got = np.array([W.whdr(refl, px, dl) for dl in DELTAS])
+        assert np.array_equal(got, d[tag + "_whdr"]), tag
+    with pytest.raises(Exception, match="1 or 3 channels"):
+        W.whdr(np.ones((2, 4, 4), np.float32), np.array([[0, 0, 1, 1, 1, 1.0]]))
+
+
+def test_load_judgements_reads_iiw_json(tmp_path):
+    doc = {"intrinsic_points": [{"id": 7, "x": 0.25, "y": 0.5, "opaque": True},
+                                {"id": 9, "x": 0.75, "y": 0.125, "opaque": True},
+                                {"id": 11, "x": 0.0, "y": 0.99, "opaque": False}],
+           "intrinsic_comparisons": [
+               {"point1": 7, "point2": 9, "darker": "1", "darker_score": 0.5},
+               {"point1": 9, "point2": 11, "darker": "E", "darker_score": 1.25},
+               {"point1": 11, "point2": 7, "darker": "2", "darker_score": 0.0625}]}
+    path = tmp_path / "123.json"
+    path.write_text(json.dumps(doc))
+    comp = W.load_judgements(str(path))
+    assert comp.dtype == np.float64
+    assert np.array_equal(comp, np.array([[0.25, 0.5, 0.75, 0.125, 1, 0.5],
+                                          [0.75, 0.125, 0.0, 0.99, 0, 1.25],
+                                          [0.0, 0.99, 0.25, 0.5, 2, 0.0625]]))
+    px = W.to_pixels(comp, 100, 200)
+    assert np.array_equal(px[:, :4], [[50, 50, 150, 12], [150, 12, 0, 99], [0, 99, 50, 50]])
+    empty = tmp_path / "e.json"
+    empty.write_text(json.dumps({"intrinsic_points": [], "intrinsic_comparisons": []}))
+    assert W.load_judgements(str(empty)).shape == (0, 6)
+
+
+@pytest.mark.gpu
+def test_device_batch_matches_reference_and_host(built):
+    import torch
+    d = np.load(os.path.join(G, "whdr.npz"))
+    for tag in TAGS:                       # one image per launch: the reference's numbers
+        refl = d[tag + "_refl"]
+        px = d[tag + "_pixels"]
+        for dl, want in zip(DELTAS, d[tag + "_whdr"]):
+            got = W.whdr_batch(torch.from_numpy(refl[None]).cuda(), [px], dl)
+            assert got.shape == (1,) and got[0] == want, (tag, dl)
+    rng = np.random.default_rng(5)
+    for c in (1, 3):                       # ragged batch against the host mirror
+        n, h, w = 9, 37, 51
+        refl = (rng.random((n, c, h, w)) ** 3).astype(np.float32)
+        comps = []
+        for i in range(n):
+            k = int(rng.integers(0, 400)) if i != 4 else 0
+            comp = np.zeros((k, 6))
+            comp[:, 0:4] = rng.random((k, 4)) * 0.999
+            comp[:, 4] = rng.integers(0, 3, k)
+            comp[:, 5] = rng.random(k)
+            comps.append(W.to_pixels(comp, h, w))
+        got = W.whdr_batch(torch.from_numpy(refl).cuda(), comps, 0.1)
+        want = np.array([W.whdr(refl[i], comps[i], 0.1) for i in range(n)])
+        assert np.array_equal(got, want), c
+    g3 = W.whdr_batch(torch.from_numpy(refl[:, 0]).cuda().contiguous(), comps, 0.1)   # [N,H,W]
+    assert g3.shape == (9,)
+    with pytest.raises(IndexError):
+        W.whdr_batch(torch.zeros((1, 1, 4, 4), device="cuda"), [np.array([[4, 0, 1, 1, 1, 1.0]])])
