@@ -86,6 +86,24 @@ def main():
                                   "ms_per_image": ms / n}
         del scene
 
+    # roofline figures on ALGORITHMIC bytes against 8 TB/s, and the VALU floor
+    # of the CNN (4,352 MACs/px as packed FMAs: 2 MACs per lane per 4 cycles, 1024 SIMDs, 2.4 GHz)
+    def hbm(entry, bytes_per_px, passes=1):
+        gbs = entry["mp_per_s"] * 1e6 * bytes_per_px * passes / 1e9
+        entry["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s",
+                             "frac": gbs / 8000.0, "algorithmic_bytes_per_px": bytes_per_px * passes}
+    for key, entry in out.items():
+        if key.startswith("gf_4k_x1"):
+            hbm(entry, 9)
+        elif key.startswith("gf_4k_x3"):
+            hbm(entry, 21)                    # guide read once per pass, u8 hand-offs: 3+3+3, +6, +6
+        elif key == "cnn_iiw":
+            hbm(entry, 8)                     # 3 in, 4 (float r) + 1 (byte r) out
+            floor_gpx = 1024 * 2.4e9 / (4352 / 2 * 4 / 64) / 1e9
+            entry["valu"] = {"bound": "packed-fma issue", "floor_gp_per_s": floor_gpx,
+                             "frac": entry["mp_per_s"] / 1e3 / floor_gpx}
+        elif key == "colorize_iiw":
+            hbm(entry, 11)                    # 3 + 4 in, 3 + 1 out
     print(json.dumps(out, indent=1))
 
 
