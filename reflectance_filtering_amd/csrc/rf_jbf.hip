@@ -552,46 +552,50 @@ __device__ __forceinline__ void jbf_tap_loop_grey4(uint32_t lut_lane_addr, uint3
     uint32_t mask = 0x00ffffffu;
     asm volatile("" : "+v"(mask));  // keep the mask in a VGPR (a literal operand is full-pipe)
 
-    for (int i = -radius; i <= radius; i++) {
+    // Row geometry: the lane's first texel address and the address of the first weight window.
+    auto row_addr = [&](int i, uint32_t &ta_out, uint32_t &wa_out, int &ngroups_out) {
         const int hw = hwtab[i + radius];
         const int hw4 = (hw + 3) & ~3;
         const int ai = i < 0 ? -i : i;
-        uint32_t ta = tile_lane_addr +
-                      (uint32_t)(((ty + i + radius) * TLW + ((r4 - hw4) >> 2)) * 4);
-        uint32_t wa_addr = sw_addr0 + (uint32_t)((ai * sw_len + (r4 + 8) + hw4 - 4) * 4);
-        const int ngroups = (hw4 >> 1) + 1;
+        ta_out = tile_lane_addr + (uint32_t)(((ty + i + radius) * TLW + ((r4 - hw4) >> 2)) * 4);
+        wa_out = sw_addr0 + (uint32_t)((ai * sw_len + (r4 + 8) + hw4 - 4) * 4);
+        ngroups_out = (hw4 >> 1) + 1;
+    };
 
-        uint32_t tq[4];
-        float4v wna, wnb;
-        float gg[2][kPix];
-        // prologue: texels of columns 0 and 1, weight window of group 0, gathers of column 0
-        asm volatile("ds_read_b32 %0, %2\n\t"
-                     "ds_read_b32 %1, %2 offset:%3"
-                     : "=&v"(tq[0]), "=&v"(tq[1])
-                     : "v"(ta), "n"(Q4 * 4));
-        asm volatile("ds_read_b128 %0, %2\n\t"
-                     "ds_read_b128 %1, %2 offset:16"
-                     : "=&v"(wna), "=&v"(wnb)
-                     : "v"(wa_addr));
-        asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(tq[0]));
-        {
-            const uint32_t tj = tq[0] & mask;
+    uint32_t tq[4];
+    float4v wna, wnb;
+    float gg[2][kPix];
+    uint32_t ta, wa_addr;
+    int ngroups;
+    row_addr(-radius, ta, wa_addr, ngroups);
+    // prologue of the first tap row: texels of columns 0 and 1, weight window of group 0,
+    // gathers of column 0.  Every later row gets these from the last group of the row before.
+    asm volatile("ds_read_b32 %0, %2\n\t"
+                 "ds_read_b32 %1, %2 offset:%3"
+                 : "=&v"(tq[0]), "=&v"(tq[1])
+                 : "v"(ta), "n"(Q4 * 4));
+    asm volatile("ds_read_b128 %0, %2\n\t"
+                 "ds_read_b128 %1, %2 offset:16"
+                 : "=&v"(wna), "=&v"(wnb)
+                 : "v"(wa_addr));
+    asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(tq[0]));
+    {
+        const uint32_t tj = tq[0] & mask;
 #pragma unroll
-            for (int p = 0; p < kPix; p++) {
-                const uint32_t a =
-                    __builtin_amdgcn_sad_u8(tj, jc[p], 0u) * (LUTREP * 4u) + lut_lane_addr;
-                asm volatile("ds_read_b32 %0, %1" : "=v"(gg[0][p]) : "v"(a));
-            }
+        for (int p = 0; p < kPix; p++) {
+            const uint32_t a = __builtin_amdgcn_sad_u8(tj, jc[p], 0u) * (LUTREP * 4u) + lut_lane_addr;
+            asm volatile("ds_read_b32 %0, %1" : "=v"(gg[0][p]) : "v"(a));
         }
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(tq[1]), "+v"(wna), "+v"(wnb), "+v"(gg[0][0]), "+v"(gg[0][1]),
-                       "+v"(gg[0][2]), "+v"(gg[0][3]));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(tq[1]), "+v"(wna), "+v"(wnb), "+v"(gg[0][0]), "+v"(gg[0][1]),
+                   "+v"(gg[0][2]), "+v"(gg[0][3]));
 
 #define RF_TEXEL_OFF4(U) (((((U) + 2) & 3) * Q4 + (((U) + 2) >> 2)) * 4)
-        // Column step U of a group: texel of column +2, SAD + gathers of column +1, accumulation
-        // of column +0.  GA = gathers being consumed, GB = gathers being issued (their registers
-        // first hold alpha, then the LDS address, then the LUT value).
-#define RF_G4_PART1(U, GA, GB)                                                                   \
+    // Column step U of a group: texel of column +2 (from address TA + OFF), SAD + gathers of
+    // column +1, accumulation of column +0.  GA = gathers being consumed, GB = gathers being
+    // issued (their registers first hold alpha, then the LDS address, then the LUT value).
+#define RF_G4_PART1(U, GA, GB, TA, OFF)                                                          \
     float w0_, w1_, w2_, w3_, s_;                                                                \
     uint32_t tj_;                                                                                \
     asm volatile("ds_read_b32 %[tn], %[ta] offset:%[off]\n\t"                                    \
@@ -608,7 +612,7 @@ __device__ __forceinline__ void jbf_tap_loop_grey4(uint32_t lut_lane_addr, uint3
                  : [tn] "=&v"(tq[((U) + 2) & 3]), [tj] "=&v"(tj_), [a0] "=&v"(GB[0]),            \
                    [a1] "=&v"(GB[1]), [a2] "=&v"(GB[2]), [a3] "=&v"(GB[3]), [w0] "=&v"(w0_),     \
                    [w1] "=&v"(w1_), [w2] "=&v"(w2_), [w3] "=&v"(w3_), [s] "=&v"(s_)              \
-                 : [ta] "v"(ta), [off] "n"(RF_TEXEL_OFF4(U)), [mask] "v"(mask),                  \
+                 : [ta] "v"(TA), [off] "n"(OFF), [mask] "v"(mask),                               \
                    [t1] "v"(tq[((U) + 1) & 3]), [t0] "v"(tq[(U)]), [jc0] "v"(jc[0]),             \
                    [jc1] "v"(jc[1]), [jc2] "v"(jc[2]), [jc3] "v"(jc[3]), [wv0] "v"(wv[4 - (U)]), \
                    [wv1] "v"(wv[5 - (U)]), [wv2] "v"(wv[6 - (U)]), [wv3] "v"(wv[7 - (U)]),       \
@@ -645,41 +649,78 @@ __device__ __forceinline__ void jbf_tap_loop_grey4(uint32_t lut_lane_addr, uint3
                    [s3] "+v"(sum[3][0]), "+v"(TN), "+v"(GB[0]), "+v"(GB[1]), "+v"(GB[2]),        \
                    "+v"(GB[3]) EXTRA_OPERANDS                                                    \
                  : [s] "v"(s_));
+#define RF_COMMA_W , "+v"(wna), "+v"(wnb)
+#define RF_LOAD_WINDOW(ADDR)                                                                     \
+    asm volatile("ds_read_b128 %0, %2\n\t"                                                       \
+                 "ds_read_b128 %1, %2 offset:16"                                                 \
+                 : "=&v"(wna), "=&v"(wnb)                                                        \
+                 : "v"(ADDR));
 
-        for (int gq = 0; gq < ngroups; gq++) {
+    for (int i = -radius; i <= radius; i++) {
+        // the row after this one (the last row prefetches itself again; the values are unused)
+        uint32_t ta_next, wa_next;
+        int ngroups_next;
+        row_addr(i < radius ? i + 1 : i, ta_next, wa_next, ngroups_next);
+
+        for (int gq = 0; gq < ngroups - 1; gq++) {
             float wv[8];
             wv[0] = wna.x; wv[1] = wna.y; wv[2] = wna.z; wv[3] = wna.w;
             wv[4] = wnb.x; wv[5] = wnb.y; wv[6] = wnb.z; wv[7] = wnb.w;
             {
-                RF_G4_PART1(0, gg[0], gg[1])
+                RF_G4_PART1(0, gg[0], gg[1], ta, RF_TEXEL_OFF4(0))
                 RF_G4_PART2(tq[2], gg[1], )
             }
             {
-                RF_G4_PART1(1, gg[1], gg[0])
+                RF_G4_PART1(1, gg[1], gg[0], ta, RF_TEXEL_OFF4(1))
                 RF_G4_PART2(tq[3], gg[0], )
             }
             {
-                RF_G4_PART1(2, gg[0], gg[1])
+                RF_G4_PART1(2, gg[0], gg[1], ta, RF_TEXEL_OFF4(2))
                 RF_G4_PART2(tq[0], gg[1], )
             }
             {
-                RF_G4_PART1(3, gg[1], gg[0])
+                RF_G4_PART1(3, gg[1], gg[0], ta, RF_TEXEL_OFF4(3))
                 // the next group's weight window rides along with this step's reads
                 wa_addr -= 16;
-                asm volatile("ds_read_b128 %0, %2\n\t"
-                             "ds_read_b128 %1, %2 offset:16"
-                             : "=&v"(wna), "=&v"(wnb)
-                             : "v"(wa_addr));
-#define RF_COMMA_W , "+v"(wna), "+v"(wnb)
+                RF_LOAD_WINDOW(wa_addr)
                 RF_G4_PART2(tq[1], gg[0], RF_COMMA_W)
-#undef RF_COMMA_W
             }
             ta += 4;
         }
+        {
+            // last group of the row: the columns past it carry no weight, so its two look-ahead
+            // reads fetch columns 0 and 1 of the NEXT row instead, step 3 issues that row's first
+            // gathers and loads its first weight window -- the next row starts with a full pipe
+            float wv[8];
+            wv[0] = wna.x; wv[1] = wna.y; wv[2] = wna.z; wv[3] = wna.w;
+            wv[4] = wnb.x; wv[5] = wnb.y; wv[6] = wnb.z; wv[7] = wnb.w;
+            {
+                RF_G4_PART1(0, gg[0], gg[1], ta, RF_TEXEL_OFF4(0))
+                RF_G4_PART2(tq[2], gg[1], )
+            }
+            {
+                RF_G4_PART1(1, gg[1], gg[0], ta, RF_TEXEL_OFF4(1))
+                RF_G4_PART2(tq[3], gg[0], )
+            }
+            {
+                RF_G4_PART1(2, gg[0], gg[1], ta_next, 0)
+                RF_G4_PART2(tq[0], gg[1], )
+            }
+            {
+                RF_G4_PART1(3, gg[1], gg[0], ta_next, Q4 * 4)
+                RF_LOAD_WINDOW(wa_next)
+                RF_G4_PART2(tq[1], gg[0], RF_COMMA_W)
+            }
+        }
+        ta = ta_next;
+        wa_addr = wa_next;
+        ngroups = ngroups_next;
+    }
+#undef RF_LOAD_WINDOW
+#undef RF_COMMA_W
 #undef RF_G4_PART1
 #undef RF_G4_PART2
 #undef RF_TEXEL_OFF4
-    }
 }
 #undef RF_LDS_READ_B64
 #undef RF_LDS_READ_B128
