@@ -183,6 +183,23 @@ def test_jbf_randomised_sweep(env):
                 (case, h, w, n, jcn, scn, border, sc, ss, d)
 
 
+@pytest.mark.parametrize("sc,ss", [(20.0, 22.0), (15.0, 28.0), (9.0, 5.0), (30.0, 23.7)])
+def test_jbf_row_pipeline(env, sc, ss):
+    """The grey tap loop carries its software pipeline from one tap row into the next (the last
+    group of a row prefetches the next row); against the compiler-scheduled loop (0x2000), the
+    64x64-only launch and the oracle, for several radii (different row shapes)."""
+    from tests import synth
+    rf, co, torch = env
+    h, w = 150, 200
+    joint = synth.scene_u8(h, w, seed=int(ss * 10))
+    grey = synth.reflectance_like_u8(h, w, seed=int(sc))[:, :, :1].copy()
+    jd, sd = _dev(torch, joint, grey)
+    got = rf.ops.joint_bilateral_u8(jd, sd, -1, sc, ss)
+    assert np.array_equal(got.cpu().numpy()[0], co.joint_bilateral_filter(joint, grey, -1, sc, ss))
+    for flags in (0x2000, 0x4000):
+        assert torch.equal(rf.ops.joint_bilateral_u8(jd, sd, -1, sc, ss, flags=flags), got), flags
+
+
 def test_jbf_strip_tiles(env):
     """Single-channel sources finish the last h % 64 rows with 32x128 / 16x256 tiles; every
     remainder class must match the oracle and the 64x64-only launch (flag 0x4000)."""
