@@ -18,6 +18,11 @@
 // the plain v_fma_f32 rate, which on gfx950 issues on the 4-cycle "full" pipe
 // (tools/microbench/valu_rates2.hip).  The channel-pair loop is kept rolled: fully unrolled,
 // hipcc hoists all 4,513 weights into SGPRs at once and spills them to VGPR lanes.
+// Scalar loads are software-pipelined by hand: the weight stream of a 32-input layer is cut into
+// chunks of 32 floats (16 k-steps of one channel pair) that alternate between two SGPR buffers;
+// each chunk's s_load is issued one chunk (32 packed FMAs) before the s_waitcnt that releases it
+// (SMEM returns out of order, so only lgkmcnt(0) is usable and nothing may be issued right
+// before a wait).  Left to hipcc the loads were issued and waited for back to back.
 #include <mutex>
 #include <vector>
 
@@ -30,10 +35,11 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 
 constexpr int kPxPerLane = 2;
 constexpr int kPackedFloats = 2 * 16 * 3 + 32 + 4 * (2 * 16 * 32 + 32) + 160 + 1;
+constexpr int kRec = 66;  // floats per channel-pair record of a 32-input layer
 // packed layout (floats):
 //   [0, 96)          layer 0 pairs: for op in 0..15, k in 0..2: {W0[2op][k], W0[2op+1][k]}
 //   [96, 128)        b0
-//   then 4 x { 1024 floats: for op in 0..15, k in 0..31: {W[2op][k], W[2op+1][k]} ; 32 bias }
+//   then 4 x 16 records of 66 floats: k in 0..31: {W[2op][k], W[2op+1][k]}, then {b[2op], b[2op+1]}
 //   then wf[160], bf
 
 __global__ void cnn_pack_weights_kernel(const float *__restrict__ w, float *__restrict__ packed)
@@ -47,12 +53,8 @@ __global__ void cnn_pack_weights_kernel(const float *__restrict__ w, float *__re
     } else if (t < 128 + 4 * 1056) {
         const int l = (t - 128) / 1056, q = (t - 128) % 1056;
         const float *wl = w + 128 + l * 1056;
-        if (q < 1024) {
-            const int op = q / 64, rem = q % 64, k = rem / 2, half = rem % 2;
-            packed[t] = wl[(2 * op + half) * 32 + k];
-        } else {
-            packed[t] = wl[q];
-        }
+        const int op = q / kRec, rem = q % kRec, k = rem / 2, half = rem % 2;
+        packed[t] = k < 32 ? wl[(2 * op + half) * 32 + k] : wl[1024 + 2 * op + half];
     } else if (t < RF_CNN_NPARAMS) {
         packed[t] = w[t];
     }
@@ -93,6 +95,67 @@ __device__ __forceinline__ void layer_pairs(const float *__restrict__ wp,
         act[2 * op + 1][lane] = float2v{fmaxf(__fadd_rn(acc[0].y, b1), 0.f),
                                         fmaxf(__fadd_rn(acc[1].y, b1), 0.f)};
     }
+}
+
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+// A 32-input layer with hand-pipelined scalar loads (see the file header).  rec = the layer's
+// 16 records of kRec floats.  Buffer A holds k = 0..15 of a channel pair, buffer B k = 16..31
+// and the two biases.
+__device__ __forceinline__ void layer32_pipelined(const float *__restrict__ rec,
+                                                  const float (&in)[kPxPerLane][32],
+                                                  float2v (*act)[kCnnThreads])
+{
+    const int lane = threadIdx.x;
+    float16v a0, a1, b0, b1;
+    float2v bias;
+#define RF_SLOAD16(DST, PTR, OFF) \
+    asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(DST) : "s"(PTR), "n"(OFF))
+#define RF_SLOAD2(DST, PTR, OFF) \
+    asm volatile("s_load_dwordx2 %0, %1, %2" : "=s"(DST) : "s"(PTR), "n"(OFF))
+#define RF_FMA16(W0, W1, KBASE)                                                              \
+    _Pragma("unroll") for (int k = 0; k < 8; k++)                                            \
+    {                                                                                        \
+        const float2v w2 = float2v{W0[2 * k], W0[2 * k + 1]};                                \
+        _Pragma("unroll") for (int p = 0; p < kPxPerLane; p++) acc[p] =                      \
+            __builtin_elementwise_fma(w2, splat(in[p][(KBASE) + k]), acc[p]);                \
+    }                                                                                        \
+    _Pragma("unroll") for (int k = 0; k < 8; k++)                                            \
+    {                                                                                        \
+        const float2v w2 = float2v{W1[2 * k], W1[2 * k + 1]};                                \
+        _Pragma("unroll") for (int p = 0; p < kPxPerLane; p++) acc[p] =                      \
+            __builtin_elementwise_fma(w2, splat(in[p][(KBASE) + 8 + k]), acc[p]);            \
+    }
+    RF_SLOAD16(a0, rec, 0);
+    RF_SLOAD16(a1, rec, 64);
+#pragma unroll 1
+    for (int op = 0; op < 16; op++) {
+        const float *cur_rec = rec + op * kRec;
+        const float *next_rec = cur_rec + (op < 15 ? kRec : 0);
+        float2v acc[kPxPerLane];
+#pragma unroll
+        for (int p = 0; p < kPxPerLane; p++)
+            acc[p] = float2v{0.f, 0.f};
+        // buffer A has had a chunk of FMAs to arrive; request B, then work on A
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1));
+        RF_SLOAD16(b0, cur_rec, 128);
+        RF_SLOAD16(b1, cur_rec, 192);
+        RF_SLOAD2(bias, cur_rec, 256);
+        RF_FMA16(a0, a1, 0)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b0), "+s"(b1), "+s"(bias));
+        RF_SLOAD16(a0, next_rec, 0);
+        RF_SLOAD16(a1, next_rec, 64);
+        RF_FMA16(b0, b1, 16)
+        act[2 * op][lane] = float2v{fmaxf(__fadd_rn(acc[0].x, bias.x), 0.f),
+                                    fmaxf(__fadd_rn(acc[1].x, bias.x), 0.f)};
+        act[2 * op + 1][lane] = float2v{fmaxf(__fadd_rn(acc[0].y, bias.y), 0.f),
+                                        fmaxf(__fadd_rn(acc[1].y, bias.y), 0.f)};
+    }
+    // the last iteration's look-ahead load must land before its registers are reused
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1));
+#undef RF_FMA16
+#undef RF_SLOAD2
+#undef RF_SLOAD16
 }
 
 // Reads the layer's activations back into registers and adds its 32 terms of the fuse dot product
@@ -140,8 +203,7 @@ __global__ __launch_bounds__(kCnnThreads) void cnn_reflectance_kernel(
         collect(act, wf, cur, z);
 #pragma unroll 1
         for (int l = 0; l < 4; l++) {
-            const float *wl = packed + 128 + l * 1056;
-            layer_pairs<32>(wl, wl + 1024, cur, act);
+            layer32_pipelined(packed + 128 + l * 1056, cur, act);
             collect(act, wf + 32 * (l + 1), cur, z);
         }
 #pragma unroll
