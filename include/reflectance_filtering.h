@@ -129,6 +129,26 @@ int rf_colorize_srgb_u8(const uint8_t *bgr, const float *r, uint8_t *refl_out, u
                         void *stream);
 
 /*
+ * CV_32F variants of the two filters (never reached by the reference's CLIs, whose images come
+ * from cv2.imread as uint8; provided so that callers which stop quantising between stages keep
+ * the cv2.ximgproc semantics).  Same layouts as the 8-bit entry points with float pixels.
+ *   rf_jbf_f32: jointBilateralFilter_32f - colour weight interpolated in a table of 4096 bins per
+ *     joint channel over the joint's value range, built on the host with libm's exp: the range
+ *     comes back to the host, so THIS ENTRY POINT SYNCHRONISES THE STREAM.  A constant joint
+ *     image returns RF_E_UNSUPPORTED (OpenCV switches to a Gaussian blur there), and so does
+ *     BORDER_CONSTANT (its zero padding indexes OpenCV's table out of bounds).
+ *   rf_gf_f32: guidedFilter on float guide/src, float result (no rounding), `iterations` chained.
+ */
+size_t rf_jbf_f32_workspace_bytes(int n, int joint_cn);
+int rf_jbf_f32(const float *joint, const float *src, float *dst, int n, int h, int w, int joint_cn,
+               int src_cn, int d, double sigma_color, double sigma_space, int border,
+               void *workspace, size_t workspace_bytes, void *stream);
+size_t rf_gf_f32_workspace_bytes(int n, int h, int w, int guide_cn, int src_cn, int radius);
+int rf_gf_f32(const float *guide, const float *src, float *dst, int n, int h, int w, int guide_cn,
+              int src_cn, int radius, double eps, int iterations, void *workspace,
+              size_t workspace_bytes, void *stream);
+
+/*
  * WHDR (weighted human disagreement rate, Bell et al. 2014) of a batch of reflectance predictions.
  * Replaces the per-comparison Python loop  whdr(reflectance, comparisons, delta)  of
  * /root/reference/training/layers/whdr_layer.py:253-287 (lightness: :180-196).

@@ -52,6 +52,12 @@ def lib():
         L.rfo_gf_u8.argtypes = [u8p, u8p, u8p, f32p] + [ctypes.c_int] * 5 + [
             ctypes.c_double, ctypes.c_int]
         L.rfo_gf_u8.restype = ctypes.c_int
+        L.rfo_jbf_f32.argtypes = [f32p, f32p, f32p] + [ctypes.c_int] * 5 + [
+            ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int]
+        L.rfo_jbf_f32.restype = ctypes.c_int
+        L.rfo_gf_f32.argtypes = [f32p, f32p, f32p] + [ctypes.c_int] * 5 + [
+            ctypes.c_double, ctypes.c_int]
+        L.rfo_gf_f32.restype = ctypes.c_int
         L.rfo_box_mean_f32.argtypes = [f32p, f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         L.rfo_box_mean_f32.restype = None
         L.rfo_srgb_lut.argtypes = [f32p]
@@ -117,6 +123,46 @@ def joint_bilateral_filter(joint, src, d, sigma_color, sigma_space, border=BORDE
                           int(threads))
     if rc != 0:
         raise ValueError("rfo_jbf_u8 rejected its arguments")
+    return out if np.ndim(src) == 3 else out[:, :, 0]
+
+
+def _as_hwc_f32(img):
+    img = np.ascontiguousarray(img, dtype=np.float32)
+    if img.ndim == 2:
+        img = img[:, :, None]
+    return img
+
+
+def joint_bilateral_filter_f32(joint, src, d, sigma_color, sigma_space, border=BORDER_DEFAULT,
+                               threads=0):
+    """cv2.ximgproc.jointBilateralFilter on float32 images (interpolated colour table)."""
+    j = _as_hwc_f32(joint)
+    s = _as_hwc_f32(src)
+    if j.shape[:2] != s.shape[:2]:
+        raise ValueError("joint and src sizes differ")
+    h, w = s.shape[:2]
+    out = np.empty_like(s)
+    rc = lib().rfo_jbf_f32(_f32(j), _f32(s), _f32(out), h, w, j.shape[2], s.shape[2], int(d),
+                           float(sigma_color), float(sigma_space), int(border), int(threads))
+    if rc == -2:
+        raise NotImplementedError("constant joint image (OpenCV falls back to a Gaussian blur)")
+    if rc != 0:
+        raise ValueError("rfo_jbf_f32 rejected its arguments")
+    return out if np.ndim(src) == 3 else out[:, :, 0]
+
+
+def guided_filter_f32(guide, src, radius, eps, threads=0):
+    """cv2.ximgproc.guidedFilter(guide, src, radius, eps) on float32 (3-channel guide)."""
+    g = _as_hwc_f32(guide)
+    s = _as_hwc_f32(src)
+    if g.shape[:2] != s.shape[:2]:
+        raise ValueError("guide and src sizes differ")
+    h, w = s.shape[:2]
+    out = np.empty_like(s)
+    rc = lib().rfo_gf_f32(_f32(g), _f32(s), _f32(out), h, w, g.shape[2], s.shape[2], int(radius),
+                          float(eps), int(threads))
+    if rc != 0:
+        raise ValueError("rfo_gf_f32 rejected its arguments")
     return out if np.ndim(src) == 3 else out[:, :, 0]
 
 

@@ -33,6 +33,7 @@
  * (-ffp-contract=off matters: every mul/add below is a separately rounded
  * IEEE-754 binary32/binary64 operation, as in an SSE2 build of OpenCV).
  */
+#include <float.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -229,6 +230,121 @@ int rfo_jbf_u8(const uint8_t *joint, const uint8_t *src, uint8_t *dst, int h, in
     return 0;
 }
 
+/*
+ * jointBilateralFilter, CV_32F joint and src (jointBilateralFilter_32f +
+ * JointBilateralFilter_32f::operator(), the structure of imgproc's bilateralFilter_32f): the colour
+ * weight is linearly interpolated in a table of 4096 bins per joint channel spanning the joint's
+ * value range.  RECALLED from the OpenCV sources, like the rest of this file.
+ * Returns 0, -1 on bad arguments, -2 when the joint is constant (OpenCV then falls back to a
+ * Gaussian blur, which is not restated here).
+ */
+int rfo_jbf_f32(const float *joint, const float *src, float *dst, int h, int w, int joint_cn,
+                int src_cn, int d, double sigma_color, double sigma_space, int border, int threads)
+{
+    if (!joint || !src || !dst || h <= 0 || w <= 0)
+        return -1;
+    if ((joint_cn != 1 && joint_cn != 3) || (src_cn != 1 && src_cn != 3))
+        return -1;
+    /* BORDER_CONSTANT pads with 0, outside the joint's value range: OpenCV's table index then
+     * runs out of bounds (undefined behaviour), so that border type is not restated */
+    if (border < 1 || border > 4)
+        return -1;
+    if (sigma_color <= 0)
+        sigma_color = 1;
+    int radius = rfo_jbf_radius(d, sigma_space);
+    int dd = 2 * radius + 1;
+    size_t npx = (size_t)h * w;
+    double minv = joint[0], maxv = joint[0];
+    for (size_t i = 0; i < npx * joint_cn; i++) {
+        if (joint[i] < minv)
+            minv = joint[i];
+        if (joint[i] > maxv)
+            maxv = joint[i];
+    }
+    if (fabs(minv - maxv) < FLT_EPSILON)
+        return -2;
+    const int bins = (1 << 12) * joint_cn;
+    float len = (float)(maxv - minv) * joint_cn;
+    float scale_index = bins / len;
+    double gauss_color_coeff = -0.5 / (sigma_color * sigma_color);
+    float *lut = (float *)malloc(sizeof(float) * (bins + 2));
+    float last = 1.f;
+    for (int i = 0; i < bins + 2; i++) {
+        if (last > 0.f) {
+            double val = i / scale_index;
+            lut[i] = (float)exp(val * val * gauss_color_coeff);
+            last = lut[i];
+        } else {
+            lut[i] = 0.f;
+        }
+    }
+    int *di = (int *)malloc(sizeof(int) * dd * dd);
+    int *dj = (int *)malloc(sizeof(int) * dd * dd);
+    float *sw = (float *)malloc(sizeof(float) * dd * dd);
+    int maxk = rfo_jbf_taps(radius, sigma_space, di, dj, sw);
+    int ph = h + 2 * radius, pw = w + 2 * radius;
+    float *jp = (float *)malloc(sizeof(float) * (size_t)ph * pw * joint_cn);
+    float *sp = (float *)malloc(sizeof(float) * (size_t)ph * pw * src_cn);
+    for (int y = 0; y < ph; y++) {
+        int sy = rfo_border_interpolate(y - radius, h, border);
+        for (int x = 0; x < pw; x++) {
+            int sx = rfo_border_interpolate(x - radius, w, border);
+            for (int c = 0; c < joint_cn; c++)
+                jp[((size_t)y * pw + x) * joint_cn + c] =
+                    (sy < 0 || sx < 0) ? 0.f : joint[((size_t)sy * w + sx) * joint_cn + c];
+            for (int c = 0; c < src_cn; c++)
+                sp[((size_t)y * pw + x) * src_cn + c] =
+                    (sy < 0 || sx < 0) ? 0.f : src[((size_t)sy * w + sx) * src_cn + c];
+        }
+    }
+    int *ofs = (int *)malloc(sizeof(int) * maxk);
+    for (int k = 0; k < maxk; k++)
+        ofs[k] = di[k] * pw + dj[k];
+#ifdef _OPENMP
+    if (threads <= 0)
+        threads = omp_get_max_threads();
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 4)
+#endif
+    for (int y = 0; y < h; y++) {
+        for (int x = 0; x < w; x++) {
+            size_t c0 = (size_t)(y + radius) * pw + (x + radius);
+            const float *jc = jp + c0 * joint_cn;
+            float sum[3] = {0.0f, 0.0f, 0.0f};
+            float wsum = 0.0f;
+            for (int k = 0; k < maxk; k++) {
+                const float *jt = jp + (c0 + ofs[k]) * joint_cn;
+                const float *st = sp + (c0 + ofs[k]) * src_cn;
+                float alpha = 0.0f;
+                for (int c = 0; c < joint_cn; c++)
+                    alpha = alpha + fabsf(jc[c] - jt[c]);
+                alpha = alpha * scale_index;
+                int idx = (int)alpha;
+                alpha = alpha - (float)idx;
+                float diff = lut[idx + 1] - lut[idx];
+                float interp = alpha * diff;
+                interp = lut[idx] + interp;
+                float weight = sw[k] * interp;
+                for (int c = 0; c < src_cn; c++) {
+                    float prod = weight * st[c];
+                    sum[c] = sum[c] + prod;
+                }
+                wsum = wsum + weight;
+            }
+            float inv = 1.0f / wsum;
+            for (int c = 0; c < src_cn; c++)
+                dst[((size_t)y * w + x) * src_cn + c] = sum[c] * inv;
+        }
+    }
+    free(ofs);
+    free(jp);
+    free(sp);
+    free(di);
+    free(dj);
+    free(sw);
+    free(lut);
+    return 0;
+}
+
 /* ------------------------------------------------------------------------- */
 /* Guided filter                                                             */
 /* ------------------------------------------------------------------------- */
@@ -334,13 +450,11 @@ static inline int sym_idx(int i, int j)
  * before the final convertTo (h*w*src_cn interleaved).
  * Follows GuidedFilterImpl::init / ::filter (guided_filter.cpp).
  */
-int rfo_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, float *q_f32, int h, int w,
-              int guide_cn, int src_cn, int radius, double eps, int threads)
+/* The filter on float data: guide_f h*w*3, src_f h*w*src_cn (interleaved); writes q_f32 and/or the
+ * uint8 conversion.  Both depths run exactly this (convertTo(CV_32F) of uint8 data is exact). */
+static int gf_core(const float *guide_f, const float *src_f, uint8_t *dst, float *q_f32, int h,
+                   int w, int src_cn, int radius, double eps, int threads)
 {
-    if (!guide || !src || (!dst && !q_f32) || h <= 0 || w <= 0 || radius < 0)
-        return -1;
-    if (guide_cn != 3 || (src_cn != 1 && src_cn != 3))
-        return -1;
     size_t n = (size_t)h * w;
 #ifdef _OPENMP
     if (threads <= 0)
@@ -353,7 +467,7 @@ int rfo_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, float *q_f
         I[c] = (float *)malloc(sizeof(float) * n);
         mI[c] = (float *)malloc(sizeof(float) * n);
         for (size_t i = 0; i < n; i++)
-            I[c][i] = (float)guide[i * 3 + c]; /* split + convertTo(CV_32F), no scaling */
+            I[c][i] = guide_f[i * 3 + c]; /* split (+ convertTo(CV_32F), no scaling) */
     }
     for (int k = 0; k < 6; k++) {
         cov[k] = (float *)malloc(sizeof(float) * n);
@@ -417,7 +531,7 @@ int rfo_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, float *q_f
     for (int s = 0; s < src_cn; s++) {
         p[s] = (float *)malloc(sizeof(float) * n);
         for (size_t i = 0; i < n; i++)
-            p[s][i] = (float)src[i * src_cn + s];
+            p[s][i] = src_f[i * src_cn + s];
         for (int g = 0; g < 3; g++) {
             cp[s][g] = (float *)malloc(sizeof(float) * n);
             al[s][g] = (float *)malloc(sizeof(float) * n);
@@ -481,6 +595,37 @@ int rfo_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, float *q_f
     for (int k = 0; k < 6; k++)
         free(inv[k]);
     return 0;
+}
+
+int rfo_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, float *q_f32, int h, int w,
+              int guide_cn, int src_cn, int radius, double eps, int threads)
+{
+    if (!guide || !src || (!dst && !q_f32) || h <= 0 || w <= 0 || radius < 0)
+        return -1;
+    if (guide_cn != 3 || (src_cn != 1 && src_cn != 3))
+        return -1;
+    size_t n = (size_t)h * w;
+    float *gf = (float *)malloc(sizeof(float) * n * 3);
+    float *sf = (float *)malloc(sizeof(float) * n * src_cn);
+    for (size_t i = 0; i < n * 3; i++)
+        gf[i] = (float)guide[i];
+    for (size_t i = 0; i < n * src_cn; i++)
+        sf[i] = (float)src[i];
+    int rc = gf_core(gf, sf, dst, q_f32, h, w, src_cn, radius, eps, threads);
+    free(gf);
+    free(sf);
+    return rc;
+}
+
+/* guidedFilter on CV_32F guide and src (dDepth = -1: float result, no rounding). */
+int rfo_gf_f32(const float *guide, const float *src, float *dst, int h, int w, int guide_cn,
+               int src_cn, int radius, double eps, int threads)
+{
+    if (!guide || !src || !dst || h <= 0 || w <= 0 || radius < 0)
+        return -1;
+    if (guide_cn != 3 || (src_cn != 1 && src_cn != 3))
+        return -1;
+    return gf_core(guide, src, NULL, dst, h, w, src_cn, radius, eps, threads);
 }
 
 /* Exposed for unit tests of the box mean alone. */

@@ -22,7 +22,8 @@ CNN_NPARAMS = 4513
 
 EXPORTS = ("rf_version", "rf_last_error", "rf_shutdown", "rf_jbf_u8", "rf_gf_workspace_bytes",
            "rf_gf_u8", "rf_cnn_reflectance_u8", "rf_colorize_workspace_bytes",
-           "rf_colorize_srgb_u8", "rf_whdr_f32")
+           "rf_colorize_srgb_u8", "rf_whdr_f32", "rf_jbf_f32_workspace_bytes", "rf_jbf_f32",
+           "rf_gf_f32_workspace_bytes", "rf_gf_f32")
 
 _lib = None
 _lock = threading.Lock()
@@ -67,6 +68,14 @@ def load_library():
         lib.rf_colorize_workspace_bytes.restype = sz
         lib.rf_colorize_srgb_u8.argtypes = [vp, vp, vp, vp, ci, ci, ci, u64, u64, vp, vp, sz, vp]
         lib.rf_colorize_srgb_u8.restype = ci
+        lib.rf_jbf_f32_workspace_bytes.argtypes = [ci, ci]
+        lib.rf_jbf_f32_workspace_bytes.restype = sz
+        lib.rf_jbf_f32.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, cd, cd, ci, vp, sz, vp]
+        lib.rf_jbf_f32.restype = ci
+        lib.rf_gf_f32_workspace_bytes.argtypes = [ci, ci, ci, ci, ci, ci]
+        lib.rf_gf_f32_workspace_bytes.restype = sz
+        lib.rf_gf_f32.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, cd, ci, vp, sz, vp]
+        lib.rf_gf_f32.restype = ci
         lib.rf_whdr_f32.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, cd, vp, vp]
         lib.rf_whdr_f32.restype = ci
         _lib = lib

@@ -85,6 +85,61 @@ __device__ constexpr int sym(int i, int j)
     return i <= j ? (i * 3 - i * (i - 1) / 2 + (j - i)) : (j * 3 - j * (j - 1) / 2 + (i - j));
 }
 
+// Per-pixel algebra of guided_filter.cpp from the 9 + 4*SCN window means m (order of Quant):
+// covariance of the guide (+eps on the diagonal), its inverse by cofactors, and for every src
+// channel s the coefficients alpha_{s,g} (out[4s + g]) and beta_s (out[4s + 3]).  Every
+// operation is the separately rounded float op of the corresponding OpenCV helper.
+template <int SCN>
+__device__ inline void gf_pixel_algebra(const float *m, float eps_f, int eps_small, float *out)
+{
+    const float *mI = m;
+    float cov[6];
+    // cov(c1,c2) = mean(I1*I2) - mean1*mean2 ; diagonal: - (mean*mean + (-eps))
+    cov[sym(0, 1)] = __fsub_rn(m[4], __fmul_rn(mI[0], mI[1]));
+    cov[sym(0, 2)] = __fsub_rn(m[5], __fmul_rn(mI[0], mI[2]));
+    cov[sym(1, 2)] = __fsub_rn(m[7], __fmul_rn(mI[1], mI[2]));
+    cov[sym(0, 0)] = __fsub_rn(m[3], __fadd_rn(__fmul_rn(mI[0], mI[0]), -eps_f));
+    cov[sym(1, 1)] = __fsub_rn(m[6], __fadd_rn(__fmul_rn(mI[1], mI[1]), -eps_f));
+    cov[sym(2, 2)] = __fsub_rn(m[8], __fadd_rn(__fmul_rn(mI[2], mI[2]), -eps_f));
+    float inv[6];
+#pragma unroll
+    for (int kk = 0; kk < 3; kk++)
+#pragma unroll
+        for (int l = 0; l <= kk; l++) {
+            const float a00 = cov[sym((kk + 1) % 3, (l + 1) % 3)];
+            const float a01 = cov[sym((kk + 1) % 3, (l + 2) % 3)];
+            const float a10 = cov[sym((kk + 2) % 3, (l + 1) % 3)];
+            const float a11 = cov[sym((kk + 2) % 3, (l + 2) % 3)];
+            inv[sym(kk, l)] = __fsub_rn(__fmul_rn(a00, a11), __fmul_rn(a01, a10));
+        }
+    float det = __fmul_rn(cov[sym(0, 0)], inv[sym(0, 0)]);
+    det = __fadd_rn(det, __fmul_rn(cov[sym(1, 0)], inv[sym(1, 0)]));
+    det = __fadd_rn(det, __fmul_rn(cov[sym(2, 0)], inv[sym(2, 0)]));
+    if (eps_small && fabsf(det) < 1e-6f)
+        det = 1.f;
+#pragma unroll
+    for (int e = 0; e < 6; e++)
+        inv[e] = __fdiv_rn(inv[e], det);
+#pragma unroll
+    for (int s = 0; s < SCN; s++) {
+        const float mp = m[9 + s];
+        float cp[3];
+#pragma unroll
+        for (int g = 0; g < 3; g++)
+            cp[g] = __fsub_rn(m[9 + SCN + 3 * s + g], __fmul_rn(mp, mI[g]));
+        float beta = mp;
+#pragma unroll
+        for (int g = 0; g < 3; g++) {
+            float a = __fmul_rn(inv[sym(g, 0)], cp[0]);
+            a = __fadd_rn(a, __fmul_rn(inv[sym(g, 1)], cp[1]));
+            a = __fadd_rn(a, __fmul_rn(inv[sym(g, 2)], cp[2]));
+            out[4 * s + g] = a;
+            beta = __fsub_rn(beta, __fmul_rn(a, mI[g]));
+        }
+        out[4 * s + 3] = beta;
+    }
+}
+
 // colour[img] != 0  <=>  some pixel of the 3-channel image has unequal channels.
 // grid: (blocks per image, images); colour[] zeroed beforehand.
 __global__ __launch_bounds__(256) void gf_grey_probe_kernel(const uint8_t *__restrict__ src,
@@ -213,53 +268,12 @@ __global__ __launch_bounds__(kAThreads) void gf_stage1_kernel(
 #pragma unroll
             for (int q = 0; q < NQ; q++)
                 m[q] = mean_of(pfx[q][c + radius + 1] - pfx[q][c - radius], scale);
-            const float *mI = m;
-            float cov[6];
-            // cov(c1,c2) = mean(I1*I2) - mean1*mean2 ; diagonal: - (mean*mean + (-eps))
-            cov[sym(0, 1)] = __fsub_rn(m[4], __fmul_rn(mI[0], mI[1]));
-            cov[sym(0, 2)] = __fsub_rn(m[5], __fmul_rn(mI[0], mI[2]));
-            cov[sym(1, 2)] = __fsub_rn(m[7], __fmul_rn(mI[1], mI[2]));
-            cov[sym(0, 0)] = __fsub_rn(m[3], __fadd_rn(__fmul_rn(mI[0], mI[0]), -eps_f));
-            cov[sym(1, 1)] = __fsub_rn(m[6], __fadd_rn(__fmul_rn(mI[1], mI[1]), -eps_f));
-            cov[sym(2, 2)] = __fsub_rn(m[8], __fadd_rn(__fmul_rn(mI[2], mI[2]), -eps_f));
-            float inv[6];
-#pragma unroll
-            for (int kk = 0; kk < 3; kk++)
-#pragma unroll
-                for (int l = 0; l <= kk; l++) {
-                    const float a00 = cov[sym((kk + 1) % 3, (l + 1) % 3)];
-                    const float a01 = cov[sym((kk + 1) % 3, (l + 2) % 3)];
-                    const float a10 = cov[sym((kk + 2) % 3, (l + 1) % 3)];
-                    const float a11 = cov[sym((kk + 2) % 3, (l + 2) % 3)];
-                    inv[sym(kk, l)] = __fsub_rn(__fmul_rn(a00, a11), __fmul_rn(a01, a10));
-                }
-            float det = __fmul_rn(cov[sym(0, 0)], inv[sym(0, 0)]);
-            det = __fadd_rn(det, __fmul_rn(cov[sym(1, 0)], inv[sym(1, 0)]));
-            det = __fadd_rn(det, __fmul_rn(cov[sym(2, 0)], inv[sym(2, 0)]));
-            if (eps_small && fabsf(det) < 1e-6f)
-                det = 1.f;
-#pragma unroll
-            for (int e = 0; e < 6; e++)
-                inv[e] = __fdiv_rn(inv[e], det);
             const size_t pix = (size_t)y * w + x;
+            float ab_px[4 * SCN];
+            gf_pixel_algebra<SCN>(m, eps_f, eps_small, ab_px);
 #pragma unroll
-            for (int s = 0; s < SCN; s++) {
-                const float mp = m[9 + s];
-                float cp[3];
-#pragma unroll
-                for (int g = 0; g < 3; g++)
-                    cp[g] = __fsub_rn(m[9 + SCN + 3 * s + g], __fmul_rn(mp, mI[g]));
-                float beta = mp;
-#pragma unroll
-                for (int g = 0; g < 3; g++) {
-                    float a = __fmul_rn(inv[sym(g, 0)], cp[0]);
-                    a = __fadd_rn(a, __fmul_rn(inv[sym(g, 1)], cp[1]));
-                    a = __fadd_rn(a, __fmul_rn(inv[sym(g, 2)], cp[2]));
-                    abimg[(size_t)(s * 4 + g) * npx + pix] = a;
-                    beta = __fsub_rn(beta, __fmul_rn(a, mI[g]));
-                }
-                abimg[(size_t)(s * 4 + 3) * npx + pix] = beta;
-            }
+            for (int e = 0; e < 4 * SCN; e++)
+                abimg[(size_t)e * npx + pix] = ab_px[e];
         }
         add_row(y - radius, false);
     }
@@ -273,10 +287,11 @@ __global__ __launch_bounds__(kAThreads) void gf_stage1_kernel(
 constexpr int kBRows = 64;
 constexpr int kBChunk = 32;
 
+// planes: [img][src_np][h][w] of which the first np per image are summed; rowsums: [img][np][h][w]
 __global__ __launch_bounds__(64) void gf_rowsum_kernel(const float *__restrict__ planes,
                                                        double *__restrict__ rowsums, int h, int w,
                                                        int radius, int row_blocks, int np,
-                                                       const int *__restrict__ colour)
+                                                       const int *__restrict__ colour, int src_np)
 {
     {
         // grey 3-channel images only carry the 4 planes of their first channel
@@ -291,7 +306,7 @@ __global__ __launch_bounds__(64) void gf_rowsum_kernel(const float *__restrict__
     const int lane = threadIdx.x;
     const int plane = blockIdx.x / row_blocks;  // plane index across the whole chunk of images
     const int row0 = (blockIdx.x - plane * row_blocks) * kBRows;
-    const float *S = planes + (size_t)plane * h * w;
+    const float *S = planes + ((size_t)(plane / np) * src_np + plane % np) * h * w;
     double *D = rowsums + (size_t)plane * h * w;
     const int ks = 2 * radius + 1;
     const int sub = lane >> 5, col = lane & 31;  // loader role: 2 rows x 32 columns per instruction
@@ -346,10 +361,11 @@ __global__ __launch_bounds__(64) void gf_rowsum_kernel(const float *__restrict__
 // top of the image; per output row the 4 means of a src channel meet in LDS and the beta
 // thread of that channel forms q = beta + a0*I0 + a1*I1 + a2*I2 and stores the byte.
 // ------------------------------------------------------------------------------------------
-template <int SCN, int SPX>
+// T = uint8_t (result rounded and saturated) or float (the CV_32F variant: result stored as is)
+template <int SCN, int SPX, typename T = uint8_t>
 __global__ __launch_bounds__(64 * 4 * SCN) void gf_colsum_apply_kernel(
-    const double *__restrict__ rowsums, const uint8_t *__restrict__ guide,
-    uint8_t *__restrict__ dst, int h, int w, int radius, const int *__restrict__ colour)
+    const double *__restrict__ rowsums, const T *__restrict__ guide, T *__restrict__ dst, int h,
+    int w, int radius, const int *__restrict__ colour)
 {
     if (wrong_variant<SCN>(colour, blockIdx.z))
         return;
@@ -363,8 +379,8 @@ __global__ __launch_bounds__(64 * 4 * SCN) void gf_colsum_apply_kernel(
     const int xc = min(x, w - 1);
     const size_t npx = (size_t)h * w;
     const double *R = rowsums + ((size_t)blockIdx.z * (4 * SPX) + plane) * npx + xc;
-    const uint8_t *gimg = guide + (size_t)blockIdx.z * npx * 3;
-    uint8_t *dimg = dst + (size_t)blockIdx.z * npx * SPX;
+    const T *gimg = guide + (size_t)blockIdx.z * npx * 3;
+    T *dimg = dst + (size_t)blockIdx.z * npx * SPX;
     const int ks = 2 * radius + 1;
     const double scale = 1.0 / (double)(ks * ks);
 
@@ -397,7 +413,11 @@ __global__ __launch_bounds__(64 * 4 * SCN) void gf_colsum_apply_kernel(
                 for (int g = 0; g < 3; g++)
                     q = __fadd_rn(q, __fmul_rn(means[y & 1][s * 4 + g][lane],
                                                (float)gimg[pix * 3 + g]));
-                const uint8_t o = saturate_u8(q);
+                T o;
+                if constexpr (sizeof(T) == 1)
+                    o = saturate_u8(q);
+                else
+                    o = q;
                 if (SCN == SPX) {
                     dimg[pix * SCN + s] = o;
                 } else {  // grey image: the one computed channel stands for all three
@@ -408,6 +428,119 @@ __global__ __launch_bounds__(64 * 4 * SCN) void gf_colsum_apply_kernel(
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// CV_32F variant.  Same operations as the uint8 path, but the stage-1 window
+// sums are no longer exact integers, so every box filter is the order-faithful pair
+// RowSum<float,double> / ColumnSum<double,float>: products -> row sums -> column sums -> means
+// -> per-pixel algebra -> row sums -> column sums + apply.
+// ------------------------------------------------------------------------------------------
+// P: [img][NQ][h][w], quantity order of Quant<SCN>
+template <int SCN>
+__global__ __launch_bounds__(256) void gff_products_kernel(const float *__restrict__ guide,
+                                                           const float *__restrict__ src,
+                                                           float *__restrict__ P, size_t npx)
+{
+    constexpr int NQ = Quant<SCN>::NQ;
+    const size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= npx)
+        return;
+    const float *g = guide + ((size_t)blockIdx.y * npx + pix) * 3;
+    const float *p = src + ((size_t)blockIdx.y * npx + pix) * SCN;
+    float *out = P + (size_t)blockIdx.y * NQ * npx + pix;
+    const float g0 = g[0], g1 = g[1], g2 = g[2];
+    out[0 * npx] = g0;
+    out[1 * npx] = g1;
+    out[2 * npx] = g2;
+    out[3 * npx] = __fmul_rn(g0, g0);
+    out[4 * npx] = __fmul_rn(g0, g1);
+    out[5 * npx] = __fmul_rn(g0, g2);
+    out[6 * npx] = __fmul_rn(g1, g1);
+    out[7 * npx] = __fmul_rn(g1, g2);
+    out[8 * npx] = __fmul_rn(g2, g2);
+#pragma unroll
+    for (int s = 0; s < SCN; s++) {
+        const float ps = p[s];
+        out[(size_t)(9 + s) * npx] = ps;
+        out[(size_t)(9 + SCN + 3 * s + 0) * npx] = __fmul_rn(ps, g0);
+        out[(size_t)(9 + SCN + 3 * s + 1) * npx] = __fmul_rn(ps, g1);
+        out[(size_t)(9 + SCN + 3 * s + 2) * npx] = __fmul_rn(ps, g2);
+    }
+}
+
+// ColumnSum<double,float>: rowsums [img][np][h][w] -> means [img][np][h][w]; one lane per column
+// of one plane.  grid (ceil(w/64), np, images)
+__global__ __launch_bounds__(64) void gff_colsum_mean_kernel(const double *__restrict__ rowsums,
+                                                             float *__restrict__ means, int h,
+                                                             int w, int radius, int np)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    if (x >= w)
+        return;
+    const size_t npx = (size_t)h * w;
+    const size_t plane = (size_t)blockIdx.z * np + blockIdx.y;
+    const double *R = rowsums + plane * npx + x;
+    float *M = means + plane * npx + x;
+    const int ks = 2 * radius + 1;
+    const double scale = 1.0 / (double)(ks * ks);
+    double SUM = 0.0;
+    for (int yy = -radius; yy < radius; yy++)
+        SUM += R[(size_t)border_interpolate(yy, h, RF_BORDER_REFLECT) * w];
+    for (int y = 0; y < h; y++) {
+        const double s0 = SUM + R[(size_t)border_interpolate(y + radius, h, RF_BORDER_REFLECT) * w];
+        M[(size_t)y * w] = (float)(s0 * scale);
+        SUM = s0 - R[(size_t)border_interpolate(y - radius, h, RF_BORDER_REFLECT) * w];
+    }
+}
+
+// means [img][NQ][h][w] -> alpha/beta in place in the first 4*SCN planes of each image
+template <int SCN>
+__global__ __launch_bounds__(256) void gff_algebra_kernel(float *__restrict__ P, size_t npx,
+                                                          float eps_f, int eps_small)
+{
+    constexpr int NQ = Quant<SCN>::NQ;
+    const size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= npx)
+        return;
+    float *base = P + (size_t)blockIdx.y * NQ * npx + pix;
+    float m[NQ], ab[4 * SCN];
+#pragma unroll
+    for (int q = 0; q < NQ; q++)
+        m[q] = base[(size_t)q * npx];
+    gf_pixel_algebra<SCN>(m, eps_f, eps_small, ab);
+#pragma unroll
+    for (int e = 0; e < 4 * SCN; e++)
+        base[(size_t)e * npx] = ab[e];
+}
+
+template <int SCN>
+int gf_f32_chunk(const float *guide, const float *src, float *dst, int m, int h, int w, int radius,
+                 float eps_f, int eps_small, int iterations, float *P, double *rows,
+                 hipStream_t stream)
+{
+    constexpr int NQ = Quant<SCN>::NQ;
+    const size_t npx = (size_t)h * w;
+    const int row_blocks = ceil_div(h, kBRows);
+    const unsigned pb = (unsigned)((npx + 255) / 256);
+    for (int it = 0; it < iterations; it++) {
+        const float *s0 = it == 0 ? src : dst;
+        hipLaunchKernelGGL(gff_products_kernel<SCN>, dim3(pb, m), dim3(256), 0, stream, guide, s0, P,
+                           npx);
+        hipLaunchKernelGGL(gf_rowsum_kernel, dim3((unsigned)(m * NQ * row_blocks)), dim3(64), 0,
+                           stream, P, rows, h, w, radius, row_blocks, NQ, (const int *)nullptr, NQ);
+        hipLaunchKernelGGL(gff_colsum_mean_kernel, dim3(ceil_div(w, 64), NQ, m), dim3(64), 0, stream,
+                           rows, P, h, w, radius, NQ);
+        hipLaunchKernelGGL(gff_algebra_kernel<SCN>, dim3(pb, m), dim3(256), 0, stream, P, npx, eps_f,
+                           eps_small);
+        hipLaunchKernelGGL(gf_rowsum_kernel, dim3((unsigned)(m * 4 * SCN * row_blocks)), dim3(64), 0,
+                           stream, P, rows, h, w, radius, row_blocks, 4 * SCN,
+                           (const int *)nullptr, NQ);
+        hipLaunchKernelGGL((gf_colsum_apply_kernel<SCN, SCN, float>), dim3(ceil_div(w, 64), 1, m),
+                           dim3(64, 4 * SCN), 0, stream, rows, guide, dst, h, w, radius,
+                           (const int *)nullptr);
+    }
+    return RF_OK;
 }
 
 }  // namespace
@@ -513,7 +646,7 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
             }
             const int row_blocks = ceil_div(h, kBRows);
             hipLaunchKernelGGL(gf_rowsum_kernel, dim3((unsigned)(m * np * row_blocks)), dim3(64), 0,
-                               stream, ab, rows, h, w, radius, row_blocks, np, colour);
+                               stream, ab, rows, h, w, radius, row_blocks, np, colour, np);
             dim3 gc(ceil_div(w, 64), 1, m);
             if (src_cn == 3) {
                 hipLaunchKernelGGL((gf_colsum_apply_kernel<3, 3>), gc, dim3(64, 12), 0, stream, rows,
@@ -525,6 +658,71 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
                                    g0, d0, h, w, radius, colour);
             }
         }
+    }
+    RF_HIP_CHECK(hipGetLastError());
+    return RF_OK;
+}
+
+extern "C" size_t rf_gf_f32_workspace_bytes(int n, int h, int w, int guide_cn, int src_cn,
+                                            int radius)
+{
+    (void)guide_cn;
+    (void)radius;
+    if (n <= 0 || h <= 0 || w <= 0 || (src_cn != 1 && src_cn != 3))
+        return 0;
+    const size_t per_img = (size_t)h * w * (9 + 4 * src_cn) * (sizeof(float) + sizeof(double));
+    size_t imgs = (size_t)n;
+    const size_t cap = (size_t)16 << 30;
+    if (imgs * per_img > cap)
+        imgs = cap / per_img;
+    if (imgs < 1)
+        imgs = 1;
+    return imgs * per_img;
+}
+
+extern "C" int rf_gf_f32(const float *guide, const float *src, float *dst, int n, int h, int w,
+                         int guide_cn, int src_cn, int radius, double eps, int iterations,
+                         void *workspace, size_t workspace_bytes, void *stream_)
+{
+    using namespace rf;
+    if (n == 0)
+        return RF_OK;
+    if (!guide || !src || !dst || !workspace)
+        return fail(RF_E_BADARG, "rf_gf_f32: NULL pointer");
+    if (n < 0 || h <= 0 || w <= 0 || iterations < 1)
+        return fail(RF_E_BADARG, "rf_gf_f32: bad size n=%d h=%d w=%d iterations=%d", n, h, w,
+                    iterations);
+    if (guide_cn != 3)
+        return fail(RF_E_UNSUPPORTED, "rf_gf_f32: guide must have 3 channels (got %d)", guide_cn);
+    if (src_cn != 1 && src_cn != 3)
+        return fail(RF_E_UNSUPPORTED, "rf_gf_f32: src channels must be 1 or 3 (got %d)", src_cn);
+    if (radius < 0 || radius > 4096)
+        return fail(RF_E_UNSUPPORTED, "rf_gf_f32: radius %d outside 0..4096", radius);
+    if (dst == guide)
+        return fail(RF_E_BADARG, "rf_gf_f32: dst must not alias guide");
+    const int nq = 9 + 4 * src_cn;
+    const size_t npx = (size_t)h * w;
+    const size_t per_img = npx * nq * (sizeof(float) + sizeof(double));
+    if (workspace_bytes < per_img)
+        return fail(RF_E_WORKSPACE, "rf_gf_f32: workspace %zu B < %zu B needed for one image",
+                    workspace_bytes, per_img);
+    hipStream_t stream = (hipStream_t)stream_;
+    int chunk = (int)std::min<size_t>((size_t)n, workspace_bytes / per_img);
+    if (chunk > 65535)
+        chunk = 65535;
+    for (int i0 = 0; i0 < n; i0 += chunk) {
+        const int m = std::min(chunk, n - i0);
+        double *rows = reinterpret_cast<double *>(workspace);
+        float *P = reinterpret_cast<float *>(rows + (size_t)m * nq * npx);
+        const float *g0 = guide + (size_t)i0 * npx * 3;
+        const float *s0 = src + (size_t)i0 * npx * src_cn;
+        float *d0 = dst + (size_t)i0 * npx * src_cn;
+        const int rc = src_cn == 3 ? gf_f32_chunk<3>(g0, s0, d0, m, h, w, radius, (float)eps,
+                                                     eps < 1e-2, iterations, P, rows, stream)
+                                   : gf_f32_chunk<1>(g0, s0, d0, m, h, w, radius, (float)eps,
+                                                     eps < 1e-2, iterations, P, rows, stream);
+        if (rc != RF_OK)
+            return rc;
     }
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;

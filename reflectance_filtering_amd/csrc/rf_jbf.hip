@@ -15,6 +15,7 @@
 //   jbf_generic_kernel untiled, any radius, global-memory gathers (fallback + cross-check).
 // Shared pieces: jbf_tap_loop (the software-pipelined tap loop, compiler-scheduled VALU) and
 // jbf_tap_loop_grey4 (its hand-interleaved form for grey tiles).
+#include <cfloat>
 #include <cmath>
 #include <mutex>
 #include <type_traits>
@@ -1214,6 +1215,106 @@ int launch_tile64_rows(const JbfTables &t, int nz, int crows, const uint8_t *joi
     return rc;
 }
 
+// ------------------------------------------------------------------------------------------
+// CV_32F variant: jointBilateralFilter_32f.  The colour weight is linearly
+// interpolated in a per-image table of 4096 bins per joint channel over the joint's value
+// range; one thread per output pixel, untiled (correctness first: no BASELINE config uses it).
+// ------------------------------------------------------------------------------------------
+constexpr int kF32BinsPerChannel = 1 << 12;
+
+// order-preserving map of a float's bits to uint32
+__device__ inline uint32_t ordered_bits(float v)
+{
+    const uint32_t b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+inline float from_ordered_bits(uint32_t k)
+{
+    const uint32_t b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    float v;
+    __builtin_memcpy(&v, &b, 4);
+    return v;
+}
+
+// minmax[2*img] = min, [2*img+1] = max (ordered bits); initialised to 0xffffffff / 0
+__global__ __launch_bounds__(256) void jbf_f32_minmax_kernel(const float *__restrict__ joint,
+                                                             uint32_t *__restrict__ minmax,
+                                                             size_t count)
+{
+    const float *p = joint + (size_t)blockIdx.y * count;
+    uint32_t lo = 0xffffffffu, hi = 0u;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t k = ordered_bits(p[i]);
+        lo = min(lo, k);
+        hi = max(hi, k);
+    }
+    atomicMin(&minmax[2 * blockIdx.y], lo);
+    atomicMax(&minmax[2 * blockIdx.y + 1], hi);
+}
+
+template <int JCN, int SCN>
+__global__ __launch_bounds__(256) void jbf_f32_kernel(
+    const float *__restrict__ joint, const float *__restrict__ src, float *__restrict__ dst, int h,
+    int w, int border, const float *__restrict__ luts, int lut_stride,
+    const float *__restrict__ scales, const int *__restrict__ di, const int *__restrict__ dj,
+    const float *__restrict__ sw, int maxk)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h)
+        return;
+    const size_t img = (size_t)blockIdx.z * h * w;
+    const float *lut = luts + (size_t)blockIdx.z * lut_stride;
+    const float scale_index = scales[blockIdx.z];
+    float j0[JCN];
+#pragma unroll
+    for (int c = 0; c < JCN; c++)
+        j0[c] = joint[(img + (size_t)y * w + x) * JCN + c];
+    float sum[SCN];
+#pragma unroll
+    for (int c = 0; c < SCN; c++)
+        sum[c] = 0.f;
+    float wsum = 0.f;
+    for (int k = 0; k < maxk; k++) {
+        const int yy = border_interpolate(y + di[k], h, border);
+        const int xx = border_interpolate(x + dj[k], w, border);
+        float jt[JCN], st[SCN];
+#pragma unroll
+        for (int c = 0; c < JCN; c++)
+            jt[c] = 0.f;
+#pragma unroll
+        for (int c = 0; c < SCN; c++)
+            st[c] = 0.f;
+        if (yy >= 0 && xx >= 0) {
+            const size_t q = img + (size_t)yy * w + xx;
+#pragma unroll
+            for (int c = 0; c < JCN; c++)
+                jt[c] = joint[q * JCN + c];
+#pragma unroll
+            for (int c = 0; c < SCN; c++)
+                st[c] = src[q * SCN + c];
+        }
+        float alpha = 0.f;
+#pragma unroll
+        for (int c = 0; c < JCN; c++)
+            alpha = __fadd_rn(alpha, fabsf(__fsub_rn(j0[c], jt[c])));
+        alpha = __fmul_rn(alpha, scale_index);
+        const int idx = (int)alpha;
+        alpha = __fsub_rn(alpha, (float)idx);
+        const float l0 = lut[idx], l1 = lut[idx + 1];
+        const float wgt = __fmul_rn(sw[k], __fadd_rn(l0, __fmul_rn(alpha, __fsub_rn(l1, l0))));
+#pragma unroll
+        for (int c = 0; c < SCN; c++)
+            sum[c] = __fadd_rn(sum[c], __fmul_rn(wgt, st[c]));
+        wsum = __fadd_rn(wsum, wgt);
+    }
+    const float inv = __fdiv_rn(1.0f, wsum);
+#pragma unroll
+    for (int c = 0; c < SCN; c++)
+        dst[(img + (size_t)y * w + x) * SCN + c] = __fmul_rn(sum[c], inv);
+}
+
 }  // namespace
 
 void jbf_shutdown()
@@ -1355,6 +1456,115 @@ extern "C" int rf_jbf_u8(const uint8_t *joint, const uint8_t *src, uint8_t *dst,
                            jcn_kernel, src_cn, border, t.d_lut, t.d_di, t.d_dj, t.d_sw, t.maxk,
                            flags);
     }
+    RF_HIP_CHECK(hipGetLastError());
+    return RF_OK;
+}
+
+extern "C" size_t rf_jbf_f32_workspace_bytes(int n, int joint_cn)
+{
+    if (n <= 0 || (joint_cn != 1 && joint_cn != 3))
+        return 0;
+    const size_t lut = (size_t)(rf::kF32BinsPerChannel * joint_cn + 2) * sizeof(float);
+    return (size_t)n * (lut + 2 * sizeof(uint32_t) + sizeof(float)) + 256;
+}
+
+extern "C" int rf_jbf_f32(const float *joint, const float *src, float *dst, int n, int h, int w,
+                          int joint_cn, int src_cn, int d, double sigma_color, double sigma_space,
+                          int border, void *workspace, size_t workspace_bytes, void *stream_)
+{
+    using namespace rf;
+    if (n == 0)
+        return RF_OK;
+    if (!joint || !src || !dst || !workspace)
+        return fail(RF_E_BADARG, "rf_jbf_f32: NULL pointer");
+    if (n < 0 || h <= 0 || w <= 0)
+        return fail(RF_E_BADARG, "rf_jbf_f32: bad size n=%d h=%d w=%d", n, h, w);
+    if ((joint_cn != 1 && joint_cn != 3) || (src_cn != 1 && src_cn != 3))
+        return fail(RF_E_UNSUPPORTED, "rf_jbf_f32: channels must be 1 or 3 (joint %d, src %d)",
+                    joint_cn, src_cn);
+    // BORDER_CONSTANT: the zero padding lies outside the joint's value range, so OpenCV's own
+    // 32F code indexes its table out of bounds there (undefined); not offered
+    if (border < 1 || border > 4)
+        return fail(RF_E_UNSUPPORTED, "rf_jbf_f32: border type %d", border);
+    if (dst == joint || dst == src)
+        return fail(RF_E_BADARG, "rf_jbf_f32: dst must not alias an input");
+    if (n > 65535)
+        return fail(RF_E_UNSUPPORTED, "rf_jbf_f32: n <= 65535 per call");
+    if (workspace_bytes < rf_jbf_f32_workspace_bytes(n, joint_cn))
+        return fail(RF_E_WORKSPACE, "rf_jbf_f32: workspace %zu B < %zu B", workspace_bytes,
+                    rf_jbf_f32_workspace_bytes(n, joint_cn));
+    if (sigma_color <= 0)
+        sigma_color = 1;
+    if (sigma_space <= 0)
+        sigma_space = 1;
+    int radius = d <= 0 ? (int)std::lrint(sigma_space * 1.5) : d / 2;
+    if (radius < 1)
+        radius = 1;
+    if (radius > 4096)
+        return fail(RF_E_UNSUPPORTED, "rf_jbf_f32: radius %d too large", radius);
+    hipStream_t stream = (hipStream_t)stream_;
+    JbfTables t;  // tap offsets and spatial weights are those of the 8-bit path
+    int rc = get_tables(radius, joint_cn, sigma_color, sigma_space, &t);
+    if (rc != RF_OK)
+        return rc;
+    // workspace: [n] (min,max) ordered bits | [n] scale_index | [n] tables
+    const int bins = kF32BinsPerChannel * joint_cn;
+    uint32_t *d_minmax = reinterpret_cast<uint32_t *>(workspace);
+    float *d_scale = reinterpret_cast<float *>(d_minmax + 2 * (size_t)n);
+    float *d_luts = reinterpret_cast<float *>(
+        static_cast<char *>(workspace) + (((size_t)n * 12 + 255) & ~(size_t)255));
+    std::vector<uint32_t> mm(2 * (size_t)n);
+    for (int i = 0; i < n; i++) {
+        mm[2 * i] = 0xffffffffu;
+        mm[2 * i + 1] = 0u;
+    }
+    RF_HIP_CHECK(hipMemcpyAsync(d_minmax, mm.data(), mm.size() * 4, hipMemcpyHostToDevice, stream));
+    const size_t count = (size_t)h * w * joint_cn;
+    const int mb = (int)std::min<size_t>(256, (count + 1023) / 1024);
+    hipLaunchKernelGGL(jbf_f32_minmax_kernel, dim3(mb, n), dim3(256), 0, stream, joint, d_minmax,
+                       count);
+    // The table depends on the joint's value range and is built with the host's exp (the same
+    // libm the CPU path uses), so the range comes back to the host: this entry point
+    // synchronises the stream.
+    RF_HIP_CHECK(hipMemcpyAsync(mm.data(), d_minmax, mm.size() * 4, hipMemcpyDeviceToHost, stream));
+    RF_HIP_CHECK(hipStreamSynchronize(stream));
+    std::vector<float> luts((size_t)n * (bins + 2)), scales(n);
+    const double gauss_color_coeff = -0.5 / (sigma_color * sigma_color);
+    for (int i = 0; i < n; i++) {
+        const double minv = from_ordered_bits(mm[2 * i]), maxv = from_ordered_bits(mm[2 * i + 1]);
+        if (std::fabs(minv - maxv) < FLT_EPSILON)
+            return fail(RF_E_UNSUPPORTED, "rf_jbf_f32: image %d has a constant joint (OpenCV falls "
+                        "back to a Gaussian blur there, which is not implemented)", i);
+        const float len = (float)(maxv - minv) * joint_cn;
+        const float scale_index = bins / len;
+        scales[i] = scale_index;
+        float *lut = luts.data() + (size_t)i * (bins + 2);
+        float last = 1.f;
+        for (int b = 0; b < bins + 2; b++) {
+            if (last > 0.f) {
+                const double val = b / scale_index;
+                lut[b] = (float)std::exp(val * val * gauss_color_coeff);
+                last = lut[b];
+            } else {
+                lut[b] = 0.f;
+            }
+        }
+    }
+    RF_HIP_CHECK(hipMemcpy(d_scale, scales.data(), scales.size() * 4, hipMemcpyHostToDevice));
+    RF_HIP_CHECK(hipMemcpy(d_luts, luts.data(), luts.size() * 4, hipMemcpyHostToDevice));
+    dim3 grid(ceil_div(w, 64), ceil_div(h, 4), n);
+#define RF_F32(J_, S_)                                                                         \
+    hipLaunchKernelGGL((jbf_f32_kernel<J_, S_>), grid, dim3(256), 0, stream, joint, src, dst, h, w, \
+                       border, d_luts, bins + 2, d_scale, t.d_di, t.d_dj, t.d_sw, t.maxk)
+    if (joint_cn == 3 && src_cn == 3)
+        RF_F32(3, 3);
+    else if (joint_cn == 3)
+        RF_F32(3, 1);
+    else if (src_cn == 3)
+        RF_F32(1, 3);
+    else
+        RF_F32(1, 1);
+#undef RF_F32
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;
 }

@@ -153,3 +153,51 @@ def colorize_srgb_u8(images, r, want_reflectance=True, want_shading=True):
                                  _ffi.current_stream_ptr(torch))
     _ffi.check(rc, "rf_colorize_srgb_u8")
     return refl, shad
+
+
+def _chk_images_f32(t, name, torch):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32
+            and t.dim() == 4 and t.is_contiguous()):
+        raise ValueError("%s must be a contiguous CUDA float32 tensor [N,H,W,C]" % name)
+
+
+def joint_bilateral_f32(joint, src, d, sigma_color, sigma_space, border=_ffi.BORDER_DEFAULT,
+                        out=None):
+    """Batched cv2.ximgproc.jointBilateralFilter on float32 images (CV_32F path: interpolated
+    colour table over each joint image's value range).  Synchronises the current stream."""
+    torch = _ffi.require_gpu()
+    lib = _ffi.load_library()
+    _chk_images_f32(joint, "joint", torch)
+    _chk_images_f32(src, "src", torch)
+    if joint.shape[:3] != src.shape[:3]:
+        raise ValueError("joint and src must have the same N,H,W")
+    if out is None:
+        out = torch.empty_like(src)
+    n, h, w, scn = src.shape
+    ws = torch.empty(max(1, lib.rf_jbf_f32_workspace_bytes(n, joint.shape[3])), dtype=torch.uint8,
+                     device=src.device)
+    rc = lib.rf_jbf_f32(joint.data_ptr(), src.data_ptr(), out.data_ptr(), n, h, w, joint.shape[3],
+                        scn, int(d), float(sigma_color), float(sigma_space), int(border),
+                        ws.data_ptr(), ws.numel(), _ffi.current_stream_ptr(torch))
+    _ffi.check(rc, "rf_jbf_f32")
+    return out
+
+
+def guided_filter_f32(guide, src, radius, eps, iterations=1, out=None):
+    """Batched cv2.ximgproc.guidedFilter on float32 guide/src: float32 result, no rounding."""
+    torch = _ffi.require_gpu()
+    lib = _ffi.load_library()
+    _chk_images_f32(guide, "guide", torch)
+    _chk_images_f32(src, "src", torch)
+    if guide.shape[:3] != src.shape[:3]:
+        raise ValueError("guide and src must have the same N,H,W")
+    if out is None:
+        out = torch.empty_like(src)
+    n, h, w, scn = src.shape
+    ws = torch.empty(max(1, lib.rf_gf_f32_workspace_bytes(n, h, w, 3, scn, int(radius))),
+                     dtype=torch.uint8, device=src.device)
+    rc = lib.rf_gf_f32(guide.data_ptr(), src.data_ptr(), out.data_ptr(), n, h, w, guide.shape[3],
+                       scn, int(radius), float(eps), int(iterations), ws.data_ptr(), ws.numel(),
+                       _ffi.current_stream_ptr(torch))
+    _ffi.check(rc, "rf_gf_f32")
+    return out

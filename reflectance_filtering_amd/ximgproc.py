@@ -12,8 +12,9 @@ from . import _ffi, ops
 
 def _to_device(img, name, torch):
     arr = np.asarray(img)
-    if arr.dtype != np.uint8:
-        raise ValueError("%s: only 8-bit images are supported (got %s)" % (name, arr.dtype))
+    if arr.dtype not in (np.uint8, np.float32):
+        raise ValueError("%s: only 8-bit and float32 images are supported (got %s)"
+                         % (name, arr.dtype))
     if arr.ndim == 2:
         arr = arr[:, :, None]
     if arr.ndim != 3 or arr.shape[2] not in (1, 3):
@@ -29,13 +30,18 @@ def _to_host(t, like):
 def jointBilateralFilter(joint, src, d, sigmaColor, sigmaSpace, dst=None,
                          borderType=_ffi.BORDER_DEFAULT):
     """cv2.ximgproc.jointBilateralFilter(joint, src, d, sigmaColor, sigmaSpace[, dst[, borderType]])
-    for uint8 images with 1 or 3 channels each."""
+    for uint8 or float32 images (both of the same depth) with 1 or 3 channels each."""
     torch = _ffi.require_gpu()
     if np.asarray(joint).shape[:2] != np.asarray(src).shape[:2]:
         raise ValueError("joint and src must have the same size")
+    if np.asarray(joint).dtype != np.asarray(src).dtype:
+        raise ValueError("joint and src must have the same depth")
     j = _to_device(joint, "joint", torch)
     s = _to_device(src, "src", torch)
-    out = ops.joint_bilateral_u8(j, s, d, sigmaColor, sigmaSpace, border=borderType)
+    if s.dtype == torch.float32:
+        out = ops.joint_bilateral_f32(j, s, d, sigmaColor, sigmaSpace, border=borderType)
+    else:
+        out = ops.joint_bilateral_u8(j, s, d, sigmaColor, sigmaSpace, border=borderType)
     res = _to_host(out, src)
     if dst is not None:
         np.copyto(dst, res)
@@ -45,15 +51,21 @@ def jointBilateralFilter(joint, src, d, sigmaColor, sigmaSpace, dst=None,
 
 def guidedFilter(guide, src, radius, eps, dst=None, dDepth=-1):
     """cv2.ximgproc.guidedFilter(guide, src, radius, eps[, dst[, dDepth]]) for a 3-channel
-    uint8 guide and a 1- or 3-channel uint8 src (dDepth must stay -1: uint8 result)."""
+    guide and a 1- or 3-channel src, both uint8 or both float32 (dDepth must stay -1: the
+    result has the depth of src)."""
     if dDepth != -1:
-        raise ValueError("guidedFilter: only dDepth=-1 (uint8 result) is supported")
+        raise ValueError("guidedFilter: only dDepth=-1 (result of src's depth) is supported")
     torch = _ffi.require_gpu()
     if np.asarray(guide).shape[:2] != np.asarray(src).shape[:2]:
         raise ValueError("guide and src must have the same size")
+    if np.asarray(guide).dtype != np.asarray(src).dtype:
+        raise ValueError("guide and src must have the same depth")
     g = _to_device(guide, "guide", torch)
     s = _to_device(src, "src", torch)
-    out = ops.guided_filter_u8(g, s, radius, eps)
+    if s.dtype == torch.float32:
+        out = ops.guided_filter_f32(g, s, radius, eps)
+    else:
+        out = ops.guided_filter_u8(g, s, radius, eps)
     res = _to_host(out, src)
     if dst is not None:
         np.copyto(dst, res)
