@@ -29,7 +29,7 @@ def timed(torch, fn, reps=3):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gf-batch", type=int, default=8)
+    ap.add_argument("--gf-batch", type=int, default=32)
     ap.add_argument("--cnn-batch", type=int, default=256)
     args = ap.parse_args()
     import torch
@@ -53,6 +53,20 @@ def main():
             out["gf_4k_x%d%s" % (iters, tag)] = {"ms": ms, "batch": n,
                                                  "mp_per_s": n * h * w / 1e6 / (ms * 1e-3)}
     del scene, grey, flat, dst
+    torch.cuda.empty_cache()
+
+    # CV_32F variants (no BASELINE config uses them): 1080p, [0,1] data
+    nf, hf, wf = 4, 1080, 1920
+    sc_u8, gr_u8 = bench.synth_batch(torch, nf, hf, wf, 5003, dev)
+    jf = sc_u8.float().div_(255.0).contiguous()
+    sf = gr_u8.float().div_(255.0).contiguous()
+    ms = timed(torch, lambda: rf.ops.guided_filter_f32(jf, sf, 45, 3.0 / 255 ** 2), reps=2)
+    out["gf_f32_1080p"] = {"ms": ms, "mp_per_s": nf * hf * wf / 1e6 / (ms * 1e-3), "batch": nf}
+    ms = timed(torch, lambda: rf.ops.joint_bilateral_f32(jf[:1], sf[:1], -1, 20 / 255.0, 22.0), reps=2)
+    out["jbf_f32_1080p"] = {"ms": ms, "mp_per_s": hf * wf / 1e6 / (ms * 1e-3), "batch": 1,
+                            "note": "untiled per-pixel kernel, includes the host round trip for "
+                                    "the value range and the table upload"}
+    del sc_u8, gr_u8, jf, sf
     torch.cuda.empty_cache()
 
     # C1-size guided filter, single image latency
@@ -102,6 +116,10 @@ def main():
             floor_gpx = 1024 * 2.4e9 / (4352 / 2 * 4 / 64) / 1e9
             entry["valu"] = {"bound": "packed-fma issue", "floor_gp_per_s": floor_gpx,
                              "frac": entry["mp_per_s"] / 1e3 / floor_gpx}
+        elif key == "gf_f32_1080p":
+            hbm(entry, 36)                    # 12 + 12 in, 12 out (float pixels)
+        elif key == "jbf_f32_1080p":
+            hbm(entry, 36)
         elif key == "colorize_iiw":
             hbm(entry, 11)                    # 3 + 4 in, 3 + 1 out
     print(json.dumps(out, indent=1))
