@@ -23,6 +23,7 @@ import argparse
 import glob
 import os
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -31,6 +32,18 @@ from . import image_utils as iu
 from . import sharding
 
 MAX_BATCH_BYTES = 2 << 30  # per group of equal-size images kept on the device at once
+IO_THREADS = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity")
+                        else (os.cpu_count() or 1)))
+
+
+def _parallel(fn, items):
+    """Image decode / encode spends its time in zlib with the GIL released: a small thread pool
+    keeps the host side from serialising a batch (results in input order)."""
+    items = list(items)
+    if len(items) < 2 or IO_THREADS < 2:
+        return [fn(it) for it in items]
+    with ThreadPoolExecutor(max_workers=IO_THREADS) as pool:
+        return list(pool.map(fn, items))
 
 
 def expand_inputs(patterns):
@@ -90,7 +103,8 @@ def filter_files(filter_type, inputs, guidance_pattern, sigma_color, sigma_spati
     import torch
     fr._check_params(filter_type, sigma_color, sigma_spatial)
     mine = my_slice(inputs, rank, world)
-    loaded = [(f, iu.imread(f), iu.imread(guidance_for(f, guidance_pattern))) for f in mine]
+    loaded = _parallel(lambda f: (f, iu.imread(f), iu.imread(guidance_for(f, guidance_pattern))),
+                       mine)
     for f, img, gui in loaded:
         if img.shape[:2] != gui.shape[:2]:
             raise ValueError("input {} and its guidance differ in size".format(f))
@@ -100,12 +114,14 @@ def filter_files(filter_type, inputs, guidance_pattern, sigma_color, sigma_spati
         joints = torch.from_numpy(np.stack([t[2] for t in group])).cuda()
         out = fr.apply_filter_batch(filter_type, images, joints, sigma_color, sigma_spatial,
                                     iterations=iterations).cpu().numpy()
+        jobs = []
         for (f, _, _), res in zip(group, out):
             name = f
             for _ in range(iterations):  # the chained CLI runs append the suffix once per pass
                 name = fr.output_filename(name, path_out, filter_type, sigma_color, sigma_spatial)
-            iu.imwrite(name, res)
+            jobs.append((name, res))
             written.append(name)
+        _parallel(lambda job: iu.imwrite(*job), jobs)
     return written
 
 
@@ -116,18 +132,20 @@ def decompose_files(inputs, path_out, rank=None, world=None):
     import torch
     from . import decompose_with_trained_CNN as dc
     mine = my_slice(inputs, rank, world)
-    loaded = [(f, iu.imread(f)) for f in mine]
+    loaded = _parallel(lambda f: (f, iu.imread(f)), mine)
     written = []
     for group in group_by_shape(loaded, lambda t: t[1].shape):
         images = torch.from_numpy(np.stack([t[1] for t in group])).cuda()
         _, r8, refl, shad = dc.decompose_batch(images)
         r8, refl, shad = r8.cpu().numpy(), refl.cpu().numpy(), shad.cpu().numpy()
+        jobs = []
         for i, (f, _) in enumerate(group):
             base = os.path.splitext(os.path.basename(f))[0]
-            iu.imwrite(os.path.join(path_out, base + "-r.png"), r8[i])
-            iu.imwrite(os.path.join(path_out, base + "-r_colorized.png"), refl[i])
-            iu.imwrite(os.path.join(path_out, base + "-s_colorized.png"), shad[i])
+            jobs.append((os.path.join(path_out, base + "-r.png"), r8[i]))
+            jobs.append((os.path.join(path_out, base + "-r_colorized.png"), refl[i]))
+            jobs.append((os.path.join(path_out, base + "-s_colorized.png"), shad[i]))
             written.append(os.path.join(path_out, base + "-r.png"))
+        _parallel(lambda job: iu.imwrite(*job), jobs)
     return written
 
 
