@@ -20,6 +20,10 @@ Fixtures (ids follow SURVEY.md section 8c):
   F4 cnn_forward.npz        decoded weights, get_reflectance_caffe(FakeNet) on two inputs
   F8 cli_plumbing.json      what apply_filter / read_filter_write / decompose_image hand to
      decompose_outputs.npz  cv2.ximgproc, cv2.imwrite and caffe (recorded calls + arrays)
+  F9 colorize_write.npz     colorize + imwrite(sRGB=True) bytes on larger inputs (pins the device
+                            colourise path, rf_colorize_srgb_u8)
+  F10 whdr.npz              training/layers/whdr_layer.py: pixel coordinates and whdr() values
+                            (pins whdr.py and rf_whdr_f32)
 """
 import hashlib
 import json
