@@ -28,6 +28,7 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 
 from . import filter_reflectance as fr
+from . import ops
 from . import image_utils as iu
 from . import sharding
 
@@ -96,6 +97,12 @@ def group_by_shape(items, shape_of, max_bytes=MAX_BATCH_BYTES):
     return groups
 
 
+def _is_grey(batch):
+    """All images of a [N,H,W,3] uint8 batch have three equal channels."""
+    return (batch.shape[-1] == 3 and np.array_equal(batch[..., 0], batch[..., 1])
+            and np.array_equal(batch[..., 1], batch[..., 2]))
+
+
 def filter_files(filter_type, inputs, guidance_pattern, sigma_color, sigma_spatial, path_out,
                  iterations=1, rank=None, world=None):
     """filter_reflectance.read_filter_write over this rank's share of `inputs`; returns the
@@ -110,10 +117,29 @@ def filter_files(filter_type, inputs, guidance_pattern, sigma_color, sigma_spati
             raise ValueError("input {} and its guidance differ in size".format(f))
     written = []
     for group in group_by_shape(loaded, lambda t: t[1].shape):
-        images = torch.from_numpy(np.stack([t[1] for t in group])).cuda()
-        joints = torch.from_numpy(np.stack([t[2] for t in group])).cuda()
-        out = fr.apply_filter_batch(filter_type, images, joints, sigma_color, sigma_spatial,
-                                    iterations=iterations).cpu().numpy()
+        imgs = np.stack([t[1] for t in group])
+        guis = np.stack([t[2] for t in group])
+        # A grey PNG comes back from imread as three equal channels (the CNN's `-r.png` always
+        # does).  The channels never mix in either filter, so such a group is filtered as one
+        # channel - a third of the transfers and of the guided filter's scratch, all tile shapes
+        # of the bilateral kernel - and replicated afterwards: identical bytes.
+        grey_src = _is_grey(imgs)
+        if grey_src:
+            imgs = imgs[..., :1]
+        images = torch.from_numpy(np.ascontiguousarray(imgs)).cuda()
+        if filter_type == "bilateral" and grey_src and _is_grey(guis):
+            joints = torch.from_numpy(np.ascontiguousarray(guis[..., :1])).cuda()
+            out = images
+            for _ in range(iterations):
+                out = ops.joint_bilateral_u8(joints, out, -1, sigma_color, sigma_spatial,
+                                             grey_as_bgr=True)
+        else:
+            joints = torch.from_numpy(guis).cuda()
+            out = fr.apply_filter_batch(filter_type, images, joints, sigma_color, sigma_spatial,
+                                        iterations=iterations)
+        out = out.cpu().numpy()
+        if grey_src:
+            out = np.repeat(out, 3, axis=3)
         jobs = []
         for (f, _, _), res in zip(group, out):
             name = f

@@ -477,6 +477,20 @@ def test_batch_front_end_matches_single_image_tools(env, tmp_path):
             cur = rf.filter_reflectance.output_filename(cur, str(single), "guided", 3.0, 9.0)
         twin = os.path.join(str(multi), os.path.basename(cur))
         assert np.array_equal(iu.imread(twin), iu.imread(cur)), cur
+    # bilateral: BF(CNN, CNN) (grey src and grey guidance: one-channel path with the guidance
+    # counted as three equal channels) and BF(CNN, photo) (grey src, colour guidance)
+    for pattern in (None, str(photos / "{base}.png")):
+        out_dir = tmp_path / ("bf_self" if pattern is None else "bf_photo")
+        out_dir.mkdir()
+        for rank in range(2):
+            batch.filter_files("bilateral", rfiles, pattern, 20.0, 5.0, str(out_dir), rank=rank,
+                               world=2)
+        for f in rfiles:
+            rf.read_filter_write("bilateral", f, batch.guidance_for(f, pattern), 20.0, 5.0,
+                                 str(single))
+            name = os.path.basename(rf.filter_reflectance.output_filename(f, str(single),
+                                                                          "bilateral", 20.0, 5.0))
+            assert np.array_equal(iu.imread(str(out_dir / name)), iu.imread(str(single / name))), name
 
 
 # ------------------------------------------------------------------------------ CLI chain
