@@ -44,6 +44,39 @@ def test_code_object_is_gfx950_only(built, tmp_path):
     assert archs == {"gfx950"}, archs
 
 
+def test_no_packed_f32_op_sel_on_scalar_operands(built, tmp_path):
+    """gfx950 hazard found while tuning the CNN: v_pk_fma_f32 with an SGPR-pair
+    source whose halves are re-routed by op_sel / op_sel_hi gives wrong results; hipcc emits
+    exactly that for a splat of an SGPR element.  No kernel in the library may contain it."""
+    tool = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(tool):
+        pytest.skip("llvm-objdump not available")
+    import glob
+    import shutil
+    copy = str(tmp_path / "librf_hip.so")
+    shutil.copy(_ffi.LIB_PATH, copy)
+    subprocess.check_output([tool, "--offloading", copy], stderr=subprocess.STDOUT)
+    bad, seen = [], 0
+    for obj in glob.glob(copy + ".*gfx950"):
+        text = subprocess.check_output([tool, "-d", obj]).decode()
+        for line in text.splitlines():
+            m = re.search(r"\b(v_pk_(?:fma|mul|add)_f32)\s+([^/]*)", line)
+            if not m:
+                continue
+            seen += 1
+            ops = m.group(2)
+            srcs = [o.strip() for o in ops.split(" op_sel")[0].split(",")][1:]
+            sel = re.search(r"op_sel:\[([0-9,]+)\]", ops)
+            sel_hi = re.search(r"op_sel_hi:\[([0-9,]+)\]", ops)
+            sel = [int(v) for v in sel.group(1).split(",")] if sel else [0] * len(srcs)
+            sel_hi = [int(v) for v in sel_hi.group(1).split(",")] if sel_hi else [1] * len(srcs)
+            for i, src in enumerate(srcs):
+                if src.startswith("s[") and i < len(sel) and (sel[i] != 0 or sel_hi[i] != 1):
+                    bad.append(line.strip())
+    assert seen > 0, "expected packed FMAs in the CNN kernel"
+    assert not bad, bad[:5]
+
+
 def test_argument_validation_needs_no_gpu(built):
     lib = _ffi.load_library()
     bufs = [ctypes.create_string_buffer(64) for _ in range(3)]
