@@ -206,3 +206,16 @@ def test_r_png_bytes_match_reference_imwrite():
     # the reference truncates r*255; 1-ulp differences in r may move a byte by one, rarely
     delta = r8.astype(int) - d["r_png"].astype(int)
     assert np.abs(delta).max() <= 1 and np.mean(delta != 0) < 0.01
+
+
+def test_box_mean_against_scipy_uniform_filter():
+    """Third-party cross-check of the box filter restatement: scipy.ndimage.uniform_filter with
+    mode='reflect' (d c b a | a b c d | d c b a) is cv::BORDER_REFLECT, the border cv::boxFilter
+    gets from guidedFilter."""
+    ndi = pytest.importorskip("scipy.ndimage")
+    rng = np.random.default_rng(21)
+    for h, w, r in ((40, 57, 3), (25, 31, 12), (9, 200, 45), (64, 64, 0)):
+        plane = (rng.random((h, w)) * 255).astype(np.float32)
+        want = ndi.uniform_filter(plane.astype(np.float64), size=2 * r + 1, mode="reflect")
+        got = co.box_mean_f32(plane, r)
+        assert np.abs(got - want).max() < 1e-3 * max(1.0, np.abs(want).max()) * 1e-1, (h, w, r)
