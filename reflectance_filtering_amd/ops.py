@@ -201,3 +201,27 @@ def guided_filter_f32(guide, src, radius, eps, iterations=1, out=None):
                        _ffi.current_stream_ptr(torch))
     _ffi.check(rc, "rf_gf_f32")
     return out
+
+
+class CapturedCall(object):
+    """A fixed sequence of operator calls captured once into a HIP graph and replayed.
+
+    The launch-bound cases (single small images: the 3x guided-filter chain is 16 launches, the
+    colourise path 18) pay one graph launch instead.  `fn` must only call operators of this
+    module on pre-allocated tensors (out= arguments, an explicit guided-filter workspace): it is
+    run once eagerly first, so that the parameter tables a call uploads on first use exist
+    before the capture, then captured on a side stream.  rf_jbf_f32 cannot be captured (it
+    synchronises).  replay() re-runs the sequence on the same buffers."""
+
+    def __init__(self, fn):
+        torch = _ffi.require_gpu()
+        self._torch = torch
+        fn()                                   # warm-up: table uploads, kernel attribute calls
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.result = fn()
+
+    def replay(self):
+        self.graph.replay()
+        return self.result

@@ -73,6 +73,16 @@ def main():
     scene, grey = bench.synth_batch(torch, 1, 256, 256, 5001, dev)
     ms = timed(torch, lambda: rf.ops.guided_filter_u8(scene, grey, 52, 7.0))
     out["gf_256_single"] = {"ms": ms}
+    # the same call, and the 3x chain, replayed from a HIP graph (launch overhead of 6 / 16 kernels)
+    o1 = torch.empty_like(grey)
+    ws = rf.ops.gf_workspace(1, 256, 256, 3, 52, dev, torch)
+    for iters in (1, 3):
+        cap = rf.ops.CapturedCall(lambda: rf.ops.guided_filter_u8(scene, grey, 52, 7.0,
+                                                                   iterations=iters, out=o1,
+                                                                   workspace=ws))
+        eager = timed(torch, lambda: rf.ops.guided_filter_u8(scene, grey, 52, 7.0, iterations=iters,
+                                                             out=o1, workspace=ws))
+        out["gf_256_single_x%d_graph" % iters] = {"ms": timed(torch, cap.replay), "eager_ms": eager}
 
     # C3: CNN + BF(CNN,CNN) at IIW size, landscape 500x333 and portrait 333x500
     for tag, (h, w) in (("iiw", (333, 500)), ("iiw_portrait", (500, 333))):
