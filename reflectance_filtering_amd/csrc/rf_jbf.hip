@@ -390,15 +390,22 @@ __device__ __forceinline__ void jbf_tap_loop(uint32_t lut_lane_addr, uint32_t sw
         else
             return t & 0x00ffffffu;
     };
+    // all four addresses first, then the four reads back to back: LDS instructions issued in
+    // a cluster disturb the VALU stream less than reads interleaved with their address math
+    // (+2.8 % on the hand-scheduled grey loop, in-process A/B)
     auto issue_gathers = [&](uint32_t jtex, float *g) {
+        uint32_t a[kPix];
 #pragma unroll
         for (int p = 0; p < kPix; p++) {
             uint32_t alpha = __builtin_amdgcn_sad_u8(jtex, jc[p], 0u);
             if (CLAMP)
                 alpha = min(alpha, amax);
-            const uint32_t a = alpha * (LUTREP * 4u) + lut_lane_addr;
-            RF_LDS_READ_B32(g[p], a);
+            a[p] = alpha * (LUTREP * 4u) + lut_lane_addr;
         }
+        asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
+#pragma unroll
+        for (int p = 0; p < kPix; p++)
+            RF_LDS_READ_B32(g[p], a[p]);
     };
     // TB == 6: second plane of 2-byte texels {G src, R src}; U = ring slot
 #define RF_READ_TEXEL(U, off_texels)                                   \
@@ -620,15 +627,15 @@ __device__ __forceinline__ void jbf_tap_loop_grey4(uint32_t lut_lane_addr, uint3
                    [g0] "v"(GA[0]), [g1] "v"(GA[1]), [g2] "v"(GA[2]), [g3] "v"(GA[3]));          \
     asm volatile("v_lshl_add_u32 %[a0], %[a0], %[sh], %[la]\n\t"                                 \
                  "v_add_f32 %[ws0], %[ws0], %[w0]\n\t"                                           \
-                 "ds_read_b32 %[a0], %[a0]\n\t"                                                  \
                  "v_lshl_add_u32 %[a1], %[a1], %[sh], %[la]\n\t"                                 \
                  "v_add_f32 %[ws1], %[ws1], %[w1]\n\t"                                           \
-                 "ds_read_b32 %[a1], %[a1]\n\t"                                                  \
                  "v_lshl_add_u32 %[a2], %[a2], %[sh], %[la]\n\t"                                 \
                  "v_add_f32 %[ws2], %[ws2], %[w2]\n\t"                                           \
-                 "ds_read_b32 %[a2], %[a2]\n\t"                                                  \
                  "v_lshl_add_u32 %[a3], %[a3], %[sh], %[la]\n\t"                                 \
                  "v_add_f32 %[ws3], %[ws3], %[w3]\n\t"                                           \
+                 "ds_read_b32 %[a0], %[a0]\n\t"                                                  \
+                 "ds_read_b32 %[a1], %[a1]\n\t"                                                  \
+                 "ds_read_b32 %[a2], %[a2]\n\t"                                                  \
                  "ds_read_b32 %[a3], %[a3]"                                                      \
                  : [a0] "+v"(GB[0]), [a1] "+v"(GB[1]), [a2] "+v"(GB[2]), [a3] "+v"(GB[3]),       \
                    [ws0] "+v"(wsum[0]), [ws1] "+v"(wsum[1]), [ws2] "+v"(wsum[2]),                \
