@@ -546,7 +546,10 @@ __device__ __forceinline__ void jbf_tap_loop(uint32_t lut_lane_addr, uint32_t sw
 // v_and_b32 on VGPRs; 2 cycles each) -- tools/microbench/valu_rates2.hip.  Per column this loop
 // needs 9 full-pipe and 17 simple instructions; hipcc emits them as an 8-instruction full-pipe
 // burst followed by the simple ones, the blocks below interleave them one for one.
-template <int LUTREP, int TLW>
+// J1: the joint has one channel and its texel field holds the value pre-multiplied by the LUT's
+// byte stride (3x that for RF_JBF_GREY_AS_BGR), so v_sad_u32(texel, centre, lane address) IS the
+// gather address: no v_lshl_add_u32, 22 instead of 26 VALU instructions per column step.
+template <int LUTREP, int TLW, bool J1 = false>
 __device__ __forceinline__ void jbf_tap_loop_grey4(uint32_t lut_lane_addr, uint32_t sw_addr0,
                                                    uint32_t tile_lane_addr,
                                                    const uint32_t (&jc)[kPix], int ty, int radius,
@@ -591,7 +594,9 @@ __device__ __forceinline__ void jbf_tap_loop_grey4(uint32_t lut_lane_addr, uint3
         const uint32_t tj = tq[0] & mask;
 #pragma unroll
         for (int p = 0; p < kPix; p++) {
-            const uint32_t a = __builtin_amdgcn_sad_u8(tj, jc[p], 0u) * (LUTREP * 4u) + lut_lane_addr;
+            const uint32_t a =
+                J1 ? (tj > jc[p] ? tj - jc[p] : jc[p] - tj) + lut_lane_addr
+                   : __builtin_amdgcn_sad_u8(tj, jc[p], 0u) * (LUTREP * 4u) + lut_lane_addr;
             asm volatile("ds_read_b32 %0, %1" : "=v"(gg[0][p]) : "v"(a));
         }
     }
@@ -642,6 +647,42 @@ __device__ __forceinline__ void jbf_tap_loop_grey4(uint32_t lut_lane_addr, uint3
                    [ws3] "+v"(wsum[3])                                                           \
                  : [sh] "n"(SHIFT), [la] "v"(lut_lane_addr), [w0] "v"(w0_), [w1] "v"(w1_),       \
                    [w2] "v"(w2_), [w3] "v"(w3_));
+    // the same step for a single-channel joint (J1): the SAD of the pre-scaled values plus the
+    // lane's LUT address is the gather address
+#define RF_G4_PART1_J1(U, GA, GB, TA, OFF)                                                       \
+    float w0_, w1_, w2_, w3_, s_;                                                                \
+    uint32_t tj_;                                                                                \
+    asm volatile("ds_read_b32 %[tn], %[ta] offset:%[off]\n\t"                                    \
+                 "v_and_b32 %[tj], %[mask], %[t1]\n\t"                                           \
+                 "v_sad_u32 %[a0], %[tj], %[jc0], %[la]\n\t"                                     \
+                 "v_mul_f32 %[w0], %[wv0], %[g0]\n\t"                                            \
+                 "v_sad_u32 %[a1], %[tj], %[jc1], %[la]\n\t"                                     \
+                 "v_mul_f32 %[w1], %[wv1], %[g1]\n\t"                                            \
+                 "v_sad_u32 %[a2], %[tj], %[jc2], %[la]\n\t"                                     \
+                 "v_mul_f32 %[w2], %[wv2], %[g2]\n\t"                                            \
+                 "v_sad_u32 %[a3], %[tj], %[jc3], %[la]\n\t"                                     \
+                 "v_mul_f32 %[w3], %[wv3], %[g3]\n\t"                                            \
+                 "v_cvt_f32_ubyte3 %[s], %[t0]"                                                  \
+                 : [tn] "=&v"(tq[((U) + 2) & 3]), [tj] "=&v"(tj_), [a0] "=&v"(GB[0]),            \
+                   [a1] "=&v"(GB[1]), [a2] "=&v"(GB[2]), [a3] "=&v"(GB[3]), [w0] "=&v"(w0_),     \
+                   [w1] "=&v"(w1_), [w2] "=&v"(w2_), [w3] "=&v"(w3_), [s] "=&v"(s_)              \
+                 : [ta] "v"(TA), [off] "n"(OFF), [mask] "v"(mask), [la] "v"(lut_lane_addr),      \
+                   [t1] "v"(tq[((U) + 1) & 3]), [t0] "v"(tq[(U)]), [jc0] "v"(jc[0]),             \
+                   [jc1] "v"(jc[1]), [jc2] "v"(jc[2]), [jc3] "v"(jc[3]), [wv0] "v"(wv[4 - (U)]), \
+                   [wv1] "v"(wv[5 - (U)]), [wv2] "v"(wv[6 - (U)]), [wv3] "v"(wv[7 - (U)]),       \
+                   [g0] "v"(GA[0]), [g1] "v"(GA[1]), [g2] "v"(GA[2]), [g3] "v"(GA[3]));          \
+    asm volatile("v_add_f32 %[ws0], %[ws0], %[w0]\n\t"                                           \
+                 "v_add_f32 %[ws1], %[ws1], %[w1]\n\t"                                           \
+                 "v_add_f32 %[ws2], %[ws2], %[w2]\n\t"                                           \
+                 "v_add_f32 %[ws3], %[ws3], %[w3]\n\t"                                           \
+                 "ds_read_b32 %[a0], %[a0]\n\t"                                                  \
+                 "ds_read_b32 %[a1], %[a1]\n\t"                                                  \
+                 "ds_read_b32 %[a2], %[a2]\n\t"                                                  \
+                 "ds_read_b32 %[a3], %[a3]"                                                      \
+                 : [a0] "+v"(GB[0]), [a1] "+v"(GB[1]), [a2] "+v"(GB[2]), [a3] "+v"(GB[3]),       \
+                   [ws0] "+v"(wsum[0]), [ws1] "+v"(wsum[1]), [ws2] "+v"(wsum[2]),                \
+                   [ws3] "+v"(wsum[3])                                                           \
+                 : [w0] "v"(w0_), [w1] "v"(w1_), [w2] "v"(w2_), [w3] "v"(w3_));
 #define RF_G4_PART2(TN, GB, EXTRA_OPERANDS)                                                      \
     asm volatile("v_mul_f32 %[w0], %[w0], %[s]\n\t"                                              \
                  "v_mul_f32 %[w1], %[w1], %[s]\n\t"                                              \
@@ -664,66 +705,72 @@ __device__ __forceinline__ void jbf_tap_loop_grey4(uint32_t lut_lane_addr, uint3
                  : "=&v"(wna), "=&v"(wnb)                                                        \
                  : "v"(ADDR));
 
-    for (int i = -radius; i <= radius; i++) {
-        // the row after this one (the last row prefetches itself again; the values are unused)
-        uint32_t ta_next, wa_next;
-        int ngroups_next;
-        row_addr(i < radius ? i + 1 : i, ta_next, wa_next, ngroups_next);
-
-        for (int gq = 0; gq < ngroups - 1; gq++) {
-            float wv[8];
-            wv[0] = wna.x; wv[1] = wna.y; wv[2] = wna.z; wv[3] = wna.w;
-            wv[4] = wnb.x; wv[5] = wnb.y; wv[6] = wnb.z; wv[7] = wnb.w;
-            {
-                RF_G4_PART1(0, gg[0], gg[1], ta, RF_TEXEL_OFF4(0))
-                RF_G4_PART2(tq[2], gg[1], )
-            }
-            {
-                RF_G4_PART1(1, gg[1], gg[0], ta, RF_TEXEL_OFF4(1))
-                RF_G4_PART2(tq[3], gg[0], )
-            }
-            {
-                RF_G4_PART1(2, gg[0], gg[1], ta, RF_TEXEL_OFF4(2))
-                RF_G4_PART2(tq[0], gg[1], )
-            }
-            {
-                RF_G4_PART1(3, gg[1], gg[0], ta, RF_TEXEL_OFF4(3))
-                // the next group's weight window rides along with this step's reads
-                wa_addr -= 16;
-                RF_LOAD_WINDOW(wa_addr)
-                RF_G4_PART2(tq[1], gg[0], RF_COMMA_W)
-            }
-            ta += 4;
-        }
-        {
-            // last group of the row: the columns past it carry no weight, so its two look-ahead
-            // reads fetch columns 0 and 1 of the NEXT row instead, step 3 issues that row's first
-            // gathers and loads its first weight window -- the next row starts with a full pipe
-            float wv[8];
-            wv[0] = wna.x; wv[1] = wna.y; wv[2] = wna.z; wv[3] = wna.w;
-            wv[4] = wnb.x; wv[5] = wnb.y; wv[6] = wnb.z; wv[7] = wnb.w;
-            {
-                RF_G4_PART1(0, gg[0], gg[1], ta, RF_TEXEL_OFF4(0))
-                RF_G4_PART2(tq[2], gg[1], )
-            }
-            {
-                RF_G4_PART1(1, gg[1], gg[0], ta, RF_TEXEL_OFF4(1))
-                RF_G4_PART2(tq[3], gg[0], )
-            }
-            {
-                RF_G4_PART1(2, gg[0], gg[1], ta_next, 0)
-                RF_G4_PART2(tq[0], gg[1], )
-            }
-            {
-                RF_G4_PART1(3, gg[1], gg[0], ta_next, Q4 * 4)
-                RF_LOAD_WINDOW(wa_next)
-                RF_G4_PART2(tq[1], gg[0], RF_COMMA_W)
-            }
-        }
-        ta = ta_next;
-        wa_addr = wa_next;
-        ngroups = ngroups_next;
+#define RF_ROW_LOOP(P1)                                                            \
+    for (int i = -radius; i <= radius; i++) {                                                       \
+        uint32_t ta_next, wa_next;                                                                  \
+        int ngroups_next;                                                                           \
+        row_addr(i < radius ? i + 1 : i, ta_next, wa_next, ngroups_next);                           \
+        for (int gq = 0; gq < ngroups - 1; gq++) {                                                  \
+            float wv[8];                                                                            \
+            wv[0] = wna.x; wv[1] = wna.y; wv[2] = wna.z; wv[3] = wna.w;                             \
+            wv[4] = wnb.x; wv[5] = wnb.y; wv[6] = wnb.z; wv[7] = wnb.w;                             \
+            {                                                                                       \
+                P1(0, gg[0], gg[1], ta, RF_TEXEL_OFF4(0))                                           \
+                RF_G4_PART2(tq[2], gg[1], )                                                         \
+            }                                                                                       \
+            {                                                                                       \
+                P1(1, gg[1], gg[0], ta, RF_TEXEL_OFF4(1))                                           \
+                RF_G4_PART2(tq[3], gg[0], )                                                         \
+            }                                                                                       \
+            {                                                                                       \
+                P1(2, gg[0], gg[1], ta, RF_TEXEL_OFF4(2))                                           \
+                RF_G4_PART2(tq[0], gg[1], )                                                         \
+            }                                                                                       \
+            {                                                                                       \
+                P1(3, gg[1], gg[0], ta, RF_TEXEL_OFF4(3))                                           \
+                wa_addr -= 16;                                                                      \
+                RF_LOAD_WINDOW(wa_addr)                                                             \
+                RF_G4_PART2(tq[1], gg[0], RF_COMMA_W)                                               \
+            }                                                                                       \
+            ta += 4;                                                                                \
+        }                                                                                           \
+        {                                                                                           \
+            float wv[8];                                                                            \
+            wv[0] = wna.x; wv[1] = wna.y; wv[2] = wna.z; wv[3] = wna.w;                             \
+            wv[4] = wnb.x; wv[5] = wnb.y; wv[6] = wnb.z; wv[7] = wnb.w;                             \
+            {                                                                                       \
+                P1(0, gg[0], gg[1], ta, RF_TEXEL_OFF4(0))                                           \
+                RF_G4_PART2(tq[2], gg[1], )                                                         \
+            }                                                                                       \
+            {                                                                                       \
+                P1(1, gg[1], gg[0], ta, RF_TEXEL_OFF4(1))                                           \
+                RF_G4_PART2(tq[3], gg[0], )                                                         \
+            }                                                                                       \
+            {                                                                                       \
+                P1(2, gg[0], gg[1], ta_next, 0)                                                     \
+                RF_G4_PART2(tq[0], gg[1], )                                                         \
+            }                                                                                       \
+            {                                                                                       \
+                P1(3, gg[1], gg[0], ta_next, Q4 * 4)                                                \
+                RF_LOAD_WINDOW(wa_next)                                                             \
+                RF_G4_PART2(tq[1], gg[0], RF_COMMA_W)                                               \
+            }                                                                                       \
+        }                                                                                           \
+        ta = ta_next;                                                                               \
+        wa_addr = wa_next;                                                                          \
+        ngroups = ngroups_next;                                                                     \
     }
+    // (per tap row: all groups but the last run the plain steps; in the last group the two
+    //  look-ahead reads fetch columns 0 and 1 of the NEXT row - the columns past the end of this
+    //  one carry no weight - step 3 issues that row's first gathers and loads its first weight
+    //  window, so the next row starts with a full pipe.  The last row prefetches itself again.)
+    if constexpr (J1) {
+        RF_ROW_LOOP(RF_G4_PART1_J1)
+    } else {
+        RF_ROW_LOOP(RF_G4_PART1)
+    }
+#undef RF_ROW_LOOP
+#undef RF_G4_PART1_J1
 #undef RF_LOAD_WINDOW
 #undef RF_COMMA_W
 #undef RF_G4_PART1
@@ -900,6 +947,11 @@ __global__ __launch_bounds__(1024) void jbf_tile64_kernel(
         lut_g[i] = lut[i / GREP];
     uint32_t *tile4 = reinterpret_cast<uint32_t *>(tile_raw);
     int grey = 1;
+    // single-channel joint and single-channel src: the joint field of a texel holds the value
+    // times the LUT's byte stride (3x for grey-as-BGR, whose colour distance is 3|d|), which
+    // turns the SAD of the tap loop into the gather address (jbf_tap_loop_grey4<.., J1 = true>)
+    const bool j1 = SCN == 1 && jcn != 3 && !(flags & 0x2000);
+    const uint32_t j1_scale = (uint32_t)(jcn < 0 ? 3 : 1) * (GREP * 4u);
     const int tlh = TH + 2 * radius;
     // one work item = 4 consecutive tile columns (4k..4k+3) of one tile row
     for (int item = tid; item < tlh * Q4; item += NT) {
@@ -911,7 +963,8 @@ __global__ __launch_bounds__(1024) void jbf_tile64_kernel(
         for (int u = 0; u < 4; u++) {
             if (SCN == 3)
                 grey &= (int)(((sv[u] ^ (sv[u] >> 8)) & 0xffffu) == 0u);
-            tile4[ry * TLW + u * Q4 + k] = jv[u] | (sv[u] << 24);
+            const uint32_t jfield = j1 ? (jv[u] & 0xffu) * j1_scale : jv[u];
+            tile4[ry * TLW + u * Q4 + k] = jfield | (sv[u] << 24);
         }
     }
     const int all_grey = block_all(grey, flag_word);  // also publishes sw table, LUT and tile
@@ -937,6 +990,9 @@ __global__ __launch_bounds__(1024) void jbf_tile64_kernel(
         if (flags & 0x2000)  // benchmark aid: compiler-scheduled loop instead of the asm one
             jbf_tap_loop<1, GREP, false, TLW, 4>(lut_lane_addr, sw_addr0, tile_lane_addr, 0u, jc, 0u,
                                                  ty, radius, r4, sw_len, hwtab, sum1, wsum);
+        else if (SCN == 1 && j1)
+            jbf_tap_loop_grey4<GREP, TLW, true>(lut_lane_addr, sw_addr0, tile_lane_addr, jc, ty,
+                                                radius, r4, sw_len, hwtab, sum1, wsum);
         else
             jbf_tap_loop_grey4<GREP, TLW>(lut_lane_addr, sw_addr0, tile_lane_addr, jc, ty, radius,
                                           r4, sw_len, hwtab, sum1, wsum);
