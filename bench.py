@@ -216,6 +216,25 @@ def main():
         rgb_ms = e0.elapsed_time(e1)
         del src_rgb
 
+    # BF(CNN, CNN) (SURVEY.md 8d input A): src and joint are the same grey map, passed as one
+    # channel with the joint counted as three equal channels - what the fused chain and the
+    # file front-ends run; identical bytes to filtering the 3-channel copies
+    grey_ms = None
+    if rank == 0 and not args.no_extras:
+        g1 = src[..., :1].contiguous()
+        g1j = g1.clone()
+        d1 = torch.empty_like(g1)
+        rf.ops.joint_bilateral_u8(g1j, g1, -1, args.sigma_color, args.sigma_spatial, out=d1,
+                                  grey_as_bgr=True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rf.ops.joint_bilateral_u8(g1j, g1, -1, args.sigma_color, args.sigma_spatial, out=d1,
+                                  grey_as_bgr=True)
+        e1.record()
+        torch.cuda.synchronize()
+        grey_ms = e0.elapsed_time(e1)
+        del g1, g1j, d1
+
     # BASELINE config C2: one 1080p image on one GPU (latency of a single launch)
     single_ms = None
     if rank == 0 and not args.no_extras:
@@ -270,6 +289,11 @@ def main():
     if single_ms:
         out["single_image"] = {"ms": single_ms, "value": h * w / 1e6 / (single_ms * 1e-3),
                                "unit": "MP/s", "note": "one %dx%d image per launch" % (w, h)}
+    if grey_ms:
+        out["grey_joint"] = {"value": launch_px / 1e6 / (grey_ms * 1e-3), "unit": "MP/s",
+                             "kernel_ms": grey_ms,
+                             "note": "BF(CNN,CNN): same launch with the grey map as joint and src, "
+                                     "1-channel buffers, joint counted as 3 equal channels"}
     if rgb_ms:
         out["colour_src"] = {"value": launch_px / 1e6 / (rgb_ms * 1e-3), "unit": "MP/s",
                              "kernel_ms": rgb_ms, "note": "same launch, 3-channel colour src"}
