@@ -347,6 +347,17 @@ __device__ inline int block_all(int pred, volatile int *word)
     return *word;
 }
 
+// Two predicates at once: bit 0 / bit 1 of the result are set iff every thread passed pred0 /
+// pred1.  `word` must have been set to 3 before an earlier barrier.
+__device__ inline int block_all2(int pred0, int pred1, int *word)
+{
+    const int keep = (pred0 ? 1 : 0) | (pred1 ? 2 : 0);
+    if (keep != 3)
+        atomicAnd(word, keep);
+    __syncthreads();
+    return *reinterpret_cast<volatile int *>(word);
+}
+
 // LDS byte address of a pointer into the workgroup's LDS (low 32 bits of the generic pointer).
 __device__ inline uint32_t lds_addr(const void *p)
 {
@@ -928,7 +939,7 @@ __global__ __launch_bounds__(1024) void jbf_tile64_kernel(
     const int sw_bytes = ((radius + 1) * sw_len * 4 + 15) & ~15;
     unsigned char *tile_raw = smem + 16 + sw_bytes;
     if (threadIdx.x == 0)
-        *flag_word = 1;
+        *flag_word = 3;
     __syncthreads();
 
     const int tid = threadIdx.x;
@@ -949,12 +960,16 @@ __global__ __launch_bounds__(1024) void jbf_tile64_kernel(
     for (int i = tid; i < nz * GREP; i += NT)
         lut_g[i] = lut[i / GREP];
     uint32_t *tile4 = reinterpret_cast<uint32_t *>(tile_raw);
-    int grey = 1;
-    // single-channel joint and single-channel src: the joint field of a texel holds the value
-    // times the LUT's byte stride (3x for grey-as-BGR, whose colour distance is 3|d|), which
-    // turns the SAD of the tap loop into the gather address (jbf_tap_loop_grey4<.., J1 = true>)
-    const bool j1 = SCN == 1 && jcn != 3 && !(flags & 0x2000);
-    const uint32_t j1_scale = (uint32_t)(jcn < 0 ? 3 : 1) * (GREP * 4u);
+    int grey = 1, grey_joint = 1;
+    // Single-channel (or grey 3-channel) joint together with a single-channel (or grey) src: the
+    // joint field of a texel holds the value times the LUT's byte stride (3x unless the joint
+    // really is one channel: the colour distance of three equal channels is 3|d|), which turns
+    // the SAD of the tap loop into the gather address (jbf_tap_loop_grey4<.., J1 = true>).
+    // Known up front for 1-channel buffers (j1): staged in that form.  For 3-channel buffers
+    // it is found out per tile, and the staged tile is then rewritten in LDS.
+    const bool j1_ok = !(flags & 0x2000);
+    const bool j1 = SCN == 1 && jcn != 3 && j1_ok;
+    const uint32_t j1_scale = (uint32_t)(jcn == 1 ? 1 : 3) * (GREP * 4u);
     const int tlh = TH + 2 * radius;
     // one work item = 4 consecutive tile columns (4k..4k+3) of one tile row
     for (int item = tid; item < tlh * Q4; item += NT) {
@@ -966,13 +981,26 @@ __global__ __launch_bounds__(1024) void jbf_tile64_kernel(
         for (int u = 0; u < 4; u++) {
             if (SCN == 3)
                 grey &= (int)(((sv[u] ^ (sv[u] >> 8)) & 0xffffu) == 0u);
+            if (jcn == 3)
+                grey_joint &= (int)(((jv[u] ^ (jv[u] >> 8)) & 0xffffu) == 0u);
             const uint32_t jfield = j1 ? (jv[u] & 0xffu) * j1_scale : jv[u];
             tile4[ry * TLW + u * Q4 + k] = jfield | (sv[u] << 24);
         }
     }
-    const int all_grey = block_all(grey, flag_word);  // also publishes sw table, LUT and tile
+    // (the barrier inside also publishes sw table, LUT and tile)
+    const int grey_bits = block_all2(grey, grey_joint, const_cast<int *>(flag_word));
+    const int all_grey = grey_bits & 1;
     if (flags & 0x1000)  // benchmark aid: staging only (tools/jbf_tune.py --stage-only)
         return;
+    // grey src and grey joint found out only now: rewrite the joint fields in place
+    const bool j1_late = !j1 && j1_ok && (SCN == 1 || all_grey) && (grey_bits & 2);
+    if (j1_late) {
+        for (int idx = tid; idx < tlh * TLW; idx += NT) {
+            const uint32_t t = tile4[idx];
+            tile4[idx] = (t & 0xffu) * j1_scale | (t & 0xff000000u);
+        }
+        __syncthreads();
+    }
 
     const uint32_t sw_addr0 = lds_addr(swl);
     if (SCN == 1 || all_grey) {
@@ -993,7 +1021,7 @@ __global__ __launch_bounds__(1024) void jbf_tile64_kernel(
         if (flags & 0x2000)  // benchmark aid: compiler-scheduled loop instead of the asm one
             jbf_tap_loop<1, GREP, false, TLW, 4>(lut_lane_addr, sw_addr0, tile_lane_addr, 0u, jc, 0u,
                                                  ty, radius, r4, sw_len, hwtab, sum1, wsum);
-        else if (SCN == 1 && j1)
+        else if (j1 || j1_late)
             jbf_tap_loop_grey4<GREP, TLW, true>(lut_lane_addr, sw_addr0, tile_lane_addr, jc, ty,
                                                 radius, r4, sw_len, hwtab, sum1, wsum);
         else

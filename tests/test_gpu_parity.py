@@ -200,6 +200,30 @@ def test_jbf_row_pipeline(env, sc, ss):
         assert torch.equal(rf.ops.joint_bilateral_u8(jd, sd, -1, sc, ss, flags=flags), got), flags
 
 
+def test_jbf_grey_joint_detected_at_run_time(env):
+    """3-channel buffers whose joint (and src) have three equal channels - BF(CNN,CNN) through
+    the 3-channel API - are recognised per tile and take the single-channel-joint loop; a tile
+    with one coloured joint pixel must not.  All channel layouts against the oracle."""
+    from tests import synth
+    rf, co, torch = env
+    h, w = 140, 200
+    g = synth.reflectance_like_u8(h, w, seed=5)               # grey, 3 equal channels
+    g2 = synth.reflectance_like_u8(h, w, seed=6)
+    almost = g.copy()
+    almost[70, 100, 1] ^= 0x08                                # one coloured pixel in one tile
+    scene = synth.scene_u8(h, w, seed=7)
+    cases = [(g, g2), (g, g), (almost, g2), (g, scene), (g[:, :, :1], g2), (g, g2[:, :, :1])]
+    for joint, src in cases:
+        jd, sd = _dev(torch, np.ascontiguousarray(joint), np.ascontiguousarray(src))
+        if jd.data_ptr() == sd.data_ptr():
+            sd = sd.clone()
+        got = rf.ops.joint_bilateral_u8(jd, sd, -1, 20.0, 22.0).cpu().numpy()[0]
+        want = co.joint_bilateral_filter(joint, src, -1, 20.0, 22.0)
+        assert np.array_equal(got, want.reshape(got.shape)), (joint.shape, src.shape)
+        assert torch.equal(rf.ops.joint_bilateral_u8(jd, sd, -1, 20.0, 22.0, flags=0x2000).cpu(),
+                           torch.from_numpy(got[None]))
+
+
 def test_jbf_strip_tiles(env):
     """Single-channel sources finish the last h % 64 rows with 32x128 / 16x256 tiles; every
     remainder class must match the oracle and the 64x64-only launch (flag 0x4000)."""
