@@ -1,19 +1,33 @@
 #!/usr/bin/env python
 """bench.py -- megapixels/s of the joint-bilateral hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config north_star|c2|c3|c4|c5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of rf_jbf_u8 (sigma_color=20, sigma_spatial=22 -> radius 33, 3,409 taps
-per pixel) over one batch of B synthetic 1920x1080 images per GPU, inputs already resident in
-HBM.  Image batches shard across GPUs with no collective (weak scaling: B per GPU is fixed);
-torch.distributed only carries the barrier and the max-over-ranks of the timed region.
-Rank 0 prints ONE JSON line with the contract fields plus `roofline` and `cpu_baseline`.
+`--gpus N` without a torchrun environment launches the N ranks itself (one child process per
+GPU, before anything touches the GPU); under torchrun it must equal WORLD_SIZE.
+
+Default workload ("north_star"): one step = one pass of rf_jbf_u8 (sigma_color=20,
+sigma_spatial=22 -> radius 33, 3,409 taps per pixel) over one batch of 256 synthetic 1920x1080
+images per GPU, inputs already resident in HBM.  Image batches shard across GPUs with no
+collective (weak scaling: the per-GPU batch is fixed); torch.distributed only carries the
+barrier and the max-over-ranks of the timed region.  Rank 0 prints ONE JSON line with the
+contract fields plus `roofline` and `cpu_baseline`, and (N = 1, default config) driver-timed lines
+for the other BASELINE configurations: `c2_single_image`, `c3_chain` (CNN -> BF(CNN,CNN), 256 IIW
+images) and `c5_gf` (3x guided filter r=45 eps=3 at 3840x2160).
+
+Other workloads, same contract (`--config`):
+    c2  one 1920x1080 image per step (BASELINE configs[1] as written)
+    c3  256 x 500x333 per GPU: uint8 BGR -> 1x1 CNN -> trunc(r*255) -> BF(CNN,CNN)
+    c4  512 x 1920x1080 joint bilateral per GPU (4096 images over 8 GPUs)
+    c5  128 x 3840x2160 per GPU, 3x guided filter c=3.0 s=45.0, piecewise-constant guide
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,27 +37,67 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 JBF_BYTES_PER_PX = 9.0         # 3 B joint + 3 B src read, 3 B dst written
+GF_BYTES_PER_PX_X3 = 21.0      # 3x chain, shared guide, uint8 hand-offs: 9 + 6 + 6
+C3_BYTES_PER_PX = 6.0          # fused chain: 3 B in, 3 B out at the cv2.imread layout
 VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
 
+CONFIGS = {
+    # name: (kind, batch per GPU, height, width)
+    "north_star": ("jbf", 256, 1080, 1920),
+    "c2": ("jbf", 1, 1080, 1920),
+    "c3": ("chain", 256, 333, 500),
+    "c4": ("jbf", 512, 1080, 1920),
+    "c5": ("gf3", 128, 2160, 3840),
+}
 
-def parse_args():
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="north_star")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step "
+                    "(default: the config's)")
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--sigma-color", type=float, default=20.0)
     ap.add_argument("--sigma-spatial", type=float, default=22.0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="target CPU time of the cpu_baseline sample (0 disables it)")
     ap.add_argument("--no-extras", "--no-colour-src", dest="no_extras", action="store_true",
-                    help="skip the secondary colour-src and single-image launches (keeps a "
-                         "profile of this command to the one timed kernel shape)")
-    return ap.parse_args()
+                    help="skip the secondary launches and the C2/C3/C5 lines (keeps a profile of "
+                         "this command to the one timed kernel shape)")
+    return ap.parse_args(argv)
 
 
+# --------------------------------------------------------------------------- self-launch
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv):
+    """Start one child per GPU (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* as torchrun would set them).
+    The parent never initialises the GPU; rank 0's stdout is this process's stdout."""
+    port = _free_port()
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv),
+                                      env=env, stdout=None if rank == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+# --------------------------------------------------------------------------- inputs
 def synth_batch(torch, n, h, w, seed, device):
     """Seeded natural-image-like inputs generated on the device: `joint` = RGB scene with
     correlated channels, `src` = grey reflectance-like map replicated to 3 channels (the
@@ -65,7 +119,7 @@ def synth_batch(torch, n, h, w, seed, device):
 
     joint = torch.empty((n, h, w, 3), dtype=torch.uint8, device=device)
     src = torch.empty((n, h, w, 3), dtype=torch.uint8, device=device)
-    step = 16
+    step = 16 if h * w <= 1080 * 1920 else 4
     for i in range(0, n, step):
         m = min(step, n - i)
         base = field(m, 1)
@@ -76,6 +130,12 @@ def synth_batch(torch, n, h, w, seed, device):
         grey = (r.clamp(0, 0.9999) * 255).floor().to(torch.uint8).permute(0, 2, 3, 1)
         src[i:i + m] = grey.expand(-1, -1, -1, 3)
     return joint.contiguous(), src.contiguous()
+
+
+def flat_guide(scene):
+    """Piecewise-constant ("L1-flattened") guidance of BASELINE config C5: the scene posterised to
+    8 levels per channel (large flat regions with sharp steps), generated on the device."""
+    return (scene // 32) * 32 + 16
 
 
 def usable_cores():
@@ -102,9 +162,53 @@ def usable_cores():
     return n
 
 
+# --------------------------------------------------------------------------- CPU baseline
+def cpu_baseline_opencv(joint0, src0, sigma_color, sigma_spatial, target_s):
+    """T2: the reference's own native call, cv2.ximgproc.jointBilateralFilter(joint, image, -1,
+    sigma_color, sigma_spatial) (/root/reference/filter_reflectance.py:60-64), default OpenCV
+    threading, on a bounded strip of image 0.  Returns None when OpenCV-contrib is not installed.
+    Also reports how the oracle compares with it (what would pin the oracle)."""
+    try:
+        import cv2
+        ximgproc = cv2.ximgproc
+        ximgproc.jointBilateralFilter
+    except (ImportError, AttributeError):
+        return None
+    import hashlib
+    import numpy as np
+    from oracle import c_oracle
+    h, w = joint0.shape[:2]
+    rows = min(h, 200)
+    t0 = time.perf_counter()
+    ximgproc.jointBilateralFilter(joint0[:rows], src0[:rows], -1, sigma_color, sigma_spatial)
+    t = time.perf_counter() - t0
+    rows = int(max(rows, min(h, rows * 0.8 * target_s / max(t, 1e-6))))
+    reps, total, out = 0, 0.0, None
+    while total < 0.6 * target_s and reps < 64:
+        t0 = time.perf_counter()
+        out = ximgproc.jointBilateralFilter(joint0[:rows], src0[:rows], -1, sigma_color,
+                                            sigma_spatial)
+        total += time.perf_counter() - t0
+        reps += 1
+    mp = reps * rows * w / 1e6
+    crop = min(rows, 96)
+    want = c_oracle.joint_bilateral_filter(joint0[:crop], src0[:crop], -1, sigma_color,
+                                           sigma_spatial, threads=usable_cores())
+    got = ximgproc.jointBilateralFilter(joint0[:crop], src0[:crop], -1, sigma_color, sigma_spatial)
+    diff = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    return {"value": mp / total, "unit": "MP/s", "cores": int(cv2.getNumThreads()),
+            "kind": "reference",
+            "sample": "%d pass(es) of cv2.ximgproc.jointBilateralFilter over a %d x %d strip of "
+                      "image 0 (%.2f MP) in %.1f s, OpenCV %s, %d threads"
+                      % (reps, rows, w, mp, total, cv2.__version__, cv2.getNumThreads()),
+            "opencv_version": cv2.__version__,
+            "opencv_build_sha256": hashlib.sha256(cv2.getBuildInformation().encode()).hexdigest(),
+            "oracle_vs_opencv": {"rows": crop, "max_abs": int(diff.max()),
+                                 "flip_rate": float((diff != 0).mean())}}
+
+
 def cpu_baseline(joint0, src0, sigma_color, sigma_spatial, target_s):
     """Oracle (CPU restatement, row-parallel OpenMP) timed on a bounded strip of one image."""
-    import numpy as np
     from oracle import c_oracle
     cores = usable_cores()
     h, w = joint0.shape[:2]
@@ -133,7 +237,8 @@ def cpu_baseline(joint0, src0, sigma_color, sigma_spatial, target_s):
     return {"value": mp / t, "unit": "MP/s", "cores": cores, "kind": "port",
             "sample": "%d pass(es) over a %d x %d strip of image 0 (%.2f MP) in %.1f s, OpenMP "
                       "threads=%d, oracle/rf_oracle.c (restatement of OpenCV's 8u joint "
-                      "bilateral, not OpenCV itself)" % (reps, hh, w, mp, t, cores)}
+                      "bilateral, not OpenCV itself: cv2.ximgproc is not installed here)"
+                      % (reps, hh, w, mp, t, cores)}
 
 
 def valu_roofline(n, h, w, radius, kernel_ms, taps_per_launch):
@@ -155,152 +260,248 @@ def valu_roofline(n, h, w, radius, kernel_ms, taps_per_launch):
             "lane_ops_per_tap": VALU_LANE_OPS_PER_S / (taps_per_launch / (kernel_ms * 1e-3))}
 
 
-def main():
-    args = parse_args()
-    import torch
-    import reflectance_filtering_amd as rf
+# --------------------------------------------------------------------------- workloads
+class Workload:
+    """One BASELINE configuration: device-resident inputs + the step that is timed."""
+
+    def __init__(self, kind, n, h, w, args, torch, rf, device, seed):
+        self.kind, self.n, self.h, self.w = kind, n, h, w
+        self.args, self.torch, self.rf = args, torch, rf
+        sc, ss = args.sigma_color, args.sigma_spatial
+        scene, grey = synth_batch(torch, n, h, w, seed, device)
+        if kind == "jbf":
+            self.joint, self.src = scene, grey
+            self.dst = torch.empty_like(grey)
+            self.step = lambda: rf.ops.joint_bilateral_u8(self.joint, self.src, -1, sc, ss,
+                                                          out=self.dst)
+            self.bytes_per_px = JBF_BYTES_PER_PX
+            radius = int(round(ss * 1.5))
+            self.name = ("joint bilateral c=%g s=%g (radius %d), batch %d x %dx%d uint8 BGR per "
+                         "GPU, RGB scene as joint, grey map as src" % (sc, ss, radius, n, w, h))
+        elif kind == "gf3":
+            self.guide, self.src = flat_guide(scene), grey
+            del scene
+            self.dst = torch.empty_like(grey)
+            self.ws = rf.ops.gf_workspace(n, h, w, 3, 45, device, torch)
+            self.step = lambda: rf.ops.guided_filter_u8(self.guide, self.src, 45, 3.0,
+                                                        iterations=3, out=self.dst,
+                                                        workspace=self.ws)
+            self.bytes_per_px = GF_BYTES_PER_PX_X3
+            self.name = ("3x guided filter c=3.0 s=45.0 (radius 45, eps 3), batch %d x %dx%d per "
+                         "GPU, piecewise-constant guide, grey map as src" % (n, w, h))
+        else:  # chain
+            self.scene = scene
+            del grey
+            self.step = lambda: rf.decompose_and_filter_batch(self.scene)
+            self.bytes_per_px = C3_BYTES_PER_PX
+            self.name = ("1x1 CNN -> trunc(r*255) -> BF(CNN,CNN) c=%g s=%g, batch %d x %dx%d per GPU"
+                         % (sc, ss, n, w, h))
+        self.pixels = float(n) * h * w
+
+    def timed_steps(self, steps, world, sharding, stub=False):
+        """barrier + sync | K steps with per-step events on the launch stream | sync + barrier."""
+        if stub:
+            sharding.barrier(world)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step()
+            sharding.barrier(world)
+            return time.perf_counter() - t0, None
+        torch = self.torch
+        torch.cuda.synchronize()
+        sharding.barrier(world)
+        torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+               for _ in range(steps)]
+        t0 = time.perf_counter()
+        for e0, e1 in evs:
+            e0.record()
+            self.step()
+            e1.record()
+        torch.cuda.synchronize()
+        sharding.barrier(world)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        return elapsed, sum(e0.elapsed_time(e1) for e0, e1 in evs) / max(1, steps)
+
+
+class StubWorkload(Workload):
+    """CPU stand-in for the kernel call (tests of the rank flow with gloo, no GPU): same pixel
+    accounting, the step only sleeps."""
+
+    def __init__(self, kind, n, h, w):
+        self.kind, self.n, self.h, self.w = kind, n, h, w
+        self.pixels = float(n) * h * w
+        self.bytes_per_px = JBF_BYTES_PER_PX
+        self.name = "stub (no kernel), batch %d x %dx%d per rank" % (n, w, h)
+        self.step = lambda: time.sleep(0.01)
+
+
+def one_shot(torch, fn, reps=1):
+    """Median-free quick timing of a secondary launch: warm once, then `reps` timed calls."""
+    fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def committed_traffic(n, h, w):
+    """HBM-side bytes per launch of the metric kernel.  NOT measured by this run: PMC counters
+    need rocprofv3 passes of their own; the value comes from the committed profile summary of the
+    same launch shape (profiles/jbf_pmc_traffic.json, written by tools/make_profiles.py)."""
+    pmc = os.path.join(ROOT, "profiles", "jbf_pmc_traffic.json")
+    try:
+        with open(pmc) as fh:
+            rec = json.load(fh)
+        if (rec.get("batch"), rec.get("height"), rec.get("width")) == (n, h, w):
+            return rec.get("hbm_bytes_per_launch"), "profiles/jbf_pmc_traffic.json"
+    except (OSError, ValueError):
+        pass
+    return None, None
+
+
+def run_rank(args):
+    stub = os.environ.get("RF_BENCH_STUB") == "1"
     from reflectance_filtering_amd import sharding
-
-    rank, world, local = sharding.init_distributed()
-    if world != args.gpus and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    torch.cuda.set_device(local % torch.cuda.device_count())
-    device = torch.device("cuda", torch.cuda.current_device())
-    rf._ffi.load_library()
-
-    n, h, w = args.batch, args.height, args.width
-    # weak scaling: every rank owns `batch` images of a global batch of world*batch
+    rank, world, local = sharding.init_distributed(backend="gloo" if stub else None)
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with matching values, or "
+                         "omit the torchrun environment to let bench.py start the ranks)"
+                         % (args.gpus, world))
+    kind, n, h, w = CONFIGS[args.config]
+    n = args.batch or n
+    h = args.height or h
+    w = args.width or w
+    # weak scaling: every rank owns `n` images of a global batch of world*n (contiguous slice)
     lo, hi = sharding.shard_range(n * world, world, rank)
     assert hi - lo == n
-    joint, src = synth_batch(torch, n, h, w, seed=1234 + 1000 * 2 + lo, device=device)
-    dst = torch.empty_like(src)
-
-    def step():
-        rf.ops.joint_bilateral_u8(joint, src, -1, args.sigma_color, args.sigma_spatial, out=dst)
+    if stub:
+        torch = rf = device = None
+        wl = StubWorkload(kind, n, h, w)
+    else:
+        import torch
+        import reflectance_filtering_amd as rf
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+        torch.cuda.set_device(local % torch.cuda.device_count())
+        device = torch.device("cuda", torch.cuda.current_device())
+        rf._ffi.load_library()
+        wl = Workload(kind, n, h, w, args, torch, rf, device, seed=1234 + 1000 * 2 + lo)
 
     for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    sharding.barrier(world)
-    torch.cuda.synchronize()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-           for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for e0, e1 in evs:
-        e0.record()
-        step()
-        e1.record()
-    torch.cuda.synchronize()
-    sharding.barrier(world)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+        wl.step()
+    elapsed, kernel_ms = wl.timed_steps(args.steps, world, sharding, stub=stub)
+    px_total, t_max = sharding.reduce_job(wl.pixels * args.steps, elapsed, world, device=device)
 
-    px_local = float(n) * h * w * args.steps
-    px_total, t_max = sharding.reduce_job(px_local, elapsed, world, device=device)
-    kernel_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / max(1, args.steps)
-
-    # secondary figure (not `value`): the same launch with a 3-channel colour src, which takes
-    # the 3-channel accumulation path (the headline src is the grey CNN-style map the reference
-    # filters, for which the kernel accumulates one channel and replicates it: identical bits)
-    rgb_ms = None
-    if rank == 0 and not args.no_extras:
+    extras = {}
+    if rank == 0 and not stub and not args.no_extras and kind == "jbf" and n > 1:
+        sc, ss = args.sigma_color, args.sigma_spatial
+        joint, src, dst = wl.joint, wl.src, wl.dst
+        # the same launch with a 3-channel colour src (3-channel accumulation; the headline src is
+        # the grey CNN-style map the reference filters, detected per tile: identical bits)
         src_rgb = joint.roll(shifts=(37, 91), dims=(1, 2)).contiguous()
-        rf.ops.joint_bilateral_u8(joint, src_rgb, -1, args.sigma_color, args.sigma_spatial, out=dst)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        rf.ops.joint_bilateral_u8(joint, src_rgb, -1, args.sigma_color, args.sigma_spatial, out=dst)
-        e1.record()
-        torch.cuda.synchronize()
-        rgb_ms = e0.elapsed_time(e1)
+        ms = one_shot(torch, lambda: rf.ops.joint_bilateral_u8(joint, src_rgb, -1, sc, ss, out=dst))
+        extras["colour_src"] = {"value": wl.pixels / 1e6 / (ms * 1e-3), "unit": "MP/s",
+                                "kernel_ms": ms, "note": "same launch, 3-channel colour src"}
         del src_rgb
-
-    # BF(CNN, CNN) (SURVEY.md 8d input A): src and joint are the same grey map, passed as one
-    # channel with the joint counted as three equal channels - what the fused chain and the
-    # file front-ends run; identical bytes to filtering the 3-channel copies
-    grey_ms = None
-    if rank == 0 and not args.no_extras:
+        # BF(CNN, CNN) (SURVEY.md 8d input A): src and joint are the same grey map, 1-channel
+        # buffers, joint counted as three equal channels (what the fused chain runs)
         g1 = src[..., :1].contiguous()
-        g1j = g1.clone()
-        d1 = torch.empty_like(g1)
-        rf.ops.joint_bilateral_u8(g1j, g1, -1, args.sigma_color, args.sigma_spatial, out=d1,
-                                  grey_as_bgr=True)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        rf.ops.joint_bilateral_u8(g1j, g1, -1, args.sigma_color, args.sigma_spatial, out=d1,
-                                  grey_as_bgr=True)
-        e1.record()
-        torch.cuda.synchronize()
-        grey_ms = e0.elapsed_time(e1)
+        g1j, d1 = g1.clone(), torch.empty_like(g1)
+        ms = one_shot(torch, lambda: rf.ops.joint_bilateral_u8(g1j, g1, -1, sc, ss, out=d1,
+                                                               grey_as_bgr=True))
+        extras["grey_joint"] = {"value": wl.pixels / 1e6 / (ms * 1e-3), "unit": "MP/s",
+                                "kernel_ms": ms,
+                                "note": "BF(CNN,CNN): grey map as joint and src, 1-channel buffers"}
         del g1, g1j, d1
-
-    # BASELINE config C2: one 1080p image on one GPU (latency of a single launch)
-    single_ms = None
-    if rank == 0 and not args.no_extras:
+        # BASELINE config C2: one 1080p image on one GPU (latency of a single launch)
         j1, s1, d1 = joint[:1].contiguous(), src[:1].contiguous(), dst[:1].contiguous()
-        rf.ops.joint_bilateral_u8(j1, s1, -1, args.sigma_color, args.sigma_spatial, out=d1)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            rf.ops.joint_bilateral_u8(j1, s1, -1, args.sigma_color, args.sigma_spatial, out=d1)
-        e1.record()
-        torch.cuda.synchronize()
-        single_ms = e0.elapsed_time(e1) / 10
+        ms = one_shot(torch, lambda: rf.ops.joint_bilateral_u8(j1, s1, -1, sc, ss, out=d1), reps=10)
+        extras["c2_single_image"] = {"ms": ms, "value": h * w / 1e6 / (ms * 1e-3), "unit": "MP/s",
+                                     "note": "one %dx%d image per launch" % (w, h)}
+        del j1, s1, d1
+    image0 = None
+    if rank == 0 and not stub and world == 1 and kind == "jbf" and args.cpu_seconds > 0:
+        image0 = (wl.joint[0].cpu().numpy(), wl.src[0].cpu().numpy())
+    if (rank == 0 and not stub and world == 1 and not args.no_extras
+            and args.config == "north_star"):
+        # driver-timed lines for the other BASELINE configurations (one GPU; not `value`)
+        del wl.joint, wl.src, wl.dst
+        torch.cuda.empty_cache()
+        for key, cfg, nb in (("c3_chain", "c3", 256), ("c5_gf", "c5", 16)):
+            k2, _, h2, w2 = CONFIGS[cfg]
+            w2l = Workload(k2, nb, h2, w2, args, torch, rf, device, seed=1234 + 1000 * int(cfg[1]))
+            w2l.step()
+            el, kms = w2l.timed_steps(3, 1, sharding)
+            gbs = w2l.pixels * w2l.bytes_per_px / (kms * 1e-3) / 1e9
+            extras[key] = {"workload": w2l.name, "value": w2l.pixels * 3 / 1e6 / el, "unit": "MP/s",
+                           "ms_per_step": el / 3 * 1e3, "steps": 3,
+                           "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                                        "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                        "algorithmic_bytes_per_px": w2l.bytes_per_px}}
+            del w2l
+            rf.ops.release_workspaces()
+            torch.cuda.empty_cache()
 
     if rank != 0:
         return
     value = px_total / 1e6 / t_max
-    radius = int(round(args.sigma_spatial * 1.5))
-    taps = sum(1 for i in range(-radius, radius + 1) for j in range(-radius, radius + 1)
-               if (i * i + j * j) ** 0.5 <= radius)
-    launch_px = float(n) * h * w
-    achieved = launch_px * JBF_BYTES_PER_PX / (kernel_ms * 1e-3) / 1e9
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "jbf_pmc_traffic.json")
-    if os.path.exists(pmc):
-        try:
-            with open(pmc) as fh:
-                rec = json.load(fh)
-            if (rec.get("batch"), rec.get("height"), rec.get("width")) == (n, h, w):
-                traffic = rec.get("hbm_bytes_per_launch")
-        except (OSError, ValueError):
-            traffic = None
+    launch_px = wl.pixels
     out = {
-        "metric": "megapixels/sec joint-bilateral sigma_c=20 sigma_s=22 @1080p",
+        "metric": {"jbf": "megapixels/sec joint-bilateral sigma_c=20 sigma_s=22 @1080p",
+                   "gf3": "megapixels/sec 3x guided filter c=3.0 s=45.0 @3840x2160 (BASELINE C5)",
+                   "chain": "megapixels/sec 1x1 CNN + BF(CNN,CNN) @IIW size (BASELINE C3)"}[kind],
         "value": value, "unit": "MP/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": t_max / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-        "data": "synthetic",
-        "config": {"workload": "joint bilateral c=%g s=%g (radius %d, %d taps/px), batch %d x "
-                               "%dx%d uint8 BGR per GPU, RGB scene as joint, grey map as src"
-                               % (args.sigma_color, args.sigma_spatial, radius, taps, n, w, h),
-                   "batch_per_gpu": n, "height": h, "width": w, "sharding": "image batch, "
-                   "contiguous slices, no collective"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "jbf_tile64_kernel<3,32,16>", "kernel_ms": kernel_ms,
-                     "algorithmic_bytes_per_launch": launch_px * JBF_BYTES_PER_PX},
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if kind != "gf3" else "f64", "data": "synthetic",
+        "config": {"workload": wl.name, "name": args.config, "batch_per_gpu": n, "height": h,
+                   "width": w, "sharding": "image batch, contiguous slices, no collective"},
+    }
+    if not stub:
+        achieved = launch_px * wl.bytes_per_px / (kernel_ms * 1e-3) / 1e9
+        traffic, source = committed_traffic(n, h, w) if kind == "jbf" else (None, None)
+        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                           "traffic_source": (source + " (rocprofv3 --pmc passes of this launch "
+                                              "shape; not measured by this run)") if source else None,
+                           "kernel": {"jbf": "jbf_tile64_kernel (name as in profiles/; the launch "
+                                             "is timed through HIP events, not identified by name)",
+                                      "gf3": "gf_stage1 + gf_rowstate + gf_colwalk, 3 passes",
+                                      "chain": "cnn_reflectance + jbf_tile64 (1-channel)"}[kind],
+                           "kernel_ms": kernel_ms,
+                           "algorithmic_bytes_per_launch": launch_px * wl.bytes_per_px}
+    if kind == "jbf" and not stub:
+        radius = int(round(args.sigma_spatial * 1.5))
+        taps = sum(1 for i in range(-radius, radius + 1) for j in range(-radius, radius + 1)
+                   if (i * i + j * j) ** 0.5 <= radius)
         # the bound that actually limits an exact brute-force bilateral: VALU issue.  The grey
         # tap loop retires 26 VALU wave-instructions per 4-output column step; a gfx950 SIMD
         # issues at most one per 2 cycles (tools/microbench/valu_rates2.hip), 1024 SIMDs, 2.4 GHz.
-        "valu": valu_roofline(n, h, w, radius, kernel_ms, launch_px * taps),
-    }
-    if single_ms:
-        out["single_image"] = {"ms": single_ms, "value": h * w / 1e6 / (single_ms * 1e-3),
-                               "unit": "MP/s", "note": "one %dx%d image per launch" % (w, h)}
-    if grey_ms:
-        out["grey_joint"] = {"value": launch_px / 1e6 / (grey_ms * 1e-3), "unit": "MP/s",
-                             "kernel_ms": grey_ms,
-                             "note": "BF(CNN,CNN): same launch with the grey map as joint and src, "
-                                     "1-channel buffers, joint counted as 3 equal channels"}
-    if rgb_ms:
-        out["colour_src"] = {"value": launch_px / 1e6 / (rgb_ms * 1e-3), "unit": "MP/s",
-                             "kernel_ms": rgb_ms, "note": "same launch, 3-channel colour src"}
-    if world == 1 and args.cpu_seconds > 0:
-        out["cpu_baseline"] = cpu_baseline(joint[0].cpu().numpy(), src[0].cpu().numpy(),
-                                           args.sigma_color, args.sigma_spatial, args.cpu_seconds)
+        out["valu"] = valu_roofline(n, h, w, radius, kernel_ms, launch_px * taps)
+        out["config"]["taps_per_px"] = taps
+    out.update(extras)
+    if image0 is not None:
+        base = cpu_baseline_opencv(image0[0], image0[1], args.sigma_color, args.sigma_spatial,
+                                   args.cpu_seconds)
+        if base is None:
+            base = cpu_baseline(image0[0], image0[1], args.sigma_color, args.sigma_spatial,
+                                args.cpu_seconds)
+        out["cpu_baseline"] = base
     print(json.dumps(out))
+    sys.stdout.flush()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, argv))
+    run_rank(args)
 
 
 if __name__ == "__main__":

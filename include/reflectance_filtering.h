@@ -46,9 +46,8 @@ extern "C" {
 #define RF_JBF_GREY_AS_BGR 4    /* a 1-channel joint counts as 3 equal channels, i.e. what cv2.imread makes of a
                                  grey PNG (colour distance 3*|d|); with a 1-channel src the 1-channel result
                                  equals every channel of the 3-channel one */
-#define RF_JBF_TUNE_SHIFT 8    /* bits 8..11: kernel-variant override used by the benchmarks; 0 = auto */
-/* bits 12..14 are benchmark / test aids that never change results except 0x1000: 0x1000 stage the
-   tile and stop (timing only), 0x2000 compiler-scheduled tap loop, 0x4000 64x64 tiles only */
+/* any other flag bit is rejected (RF_E_BADARG); test and benchmark switches live in
+   reflectance_filtering_debug.h */
 
 int rf_version(void);
 const char *rf_last_error(void);
@@ -61,7 +60,7 @@ int rf_shutdown(void);
  * as called at /root/reference/filter_reflectance.py:60-64 (d = -1).
  *   joint  n*h*w*joint_cn   device, joint_cn in {1,3}
  *   src    n*h*w*src_cn     device, src_cn   in {1,3}
- *   dst    n*h*w*src_cn     device, must not alias joint or src
+ *   dst    n*h*w*src_cn     device, must not overlap joint or src
  *   d <= 0 -> radius = cvRound(1.5*sigma_space), else radius = d/2; radius >= 1
  * Per pixel the taps are accumulated in OpenCV's order (row-major over the
  * disk, float32, separately rounded multiply and add), so the uint8 result is

@@ -1,0 +1,32 @@
+/*
+ * reflectance_filtering_debug.h -- test and benchmark switches of librf_hip.so.
+ *
+ * NOT part of the drop-in boundary (include/reflectance_filtering.h): nothing here is needed
+ * to replace the reference's native calls.  The switches select alternative kernels that the
+ * parity tests and the timing tools compare against the default ones; they are process-global,
+ * not meant to be flipped while other threads are inside the library, and all default to 0.
+ *
+ *   "gf_two_kernel"      guided filter: row-sum / column-sum kernel pair for every radius (the
+ *                        default fuses stage 2 for radius 45 and 52); identical bytes
+ *   "jbf_compiler_loop"  joint bilateral: compiler-scheduled tap loop; identical bytes
+ *   "jbf_tile64_only"    joint bilateral: no strip tiles at the image remainder; identical bytes
+ *   "jbf_tune"           joint bilateral: kernel-variant override 1..7 (tools/jbf_tune.py)
+ *   "jbf_f32_untiled"    float joint bilateral: one-thread-per-pixel kernel; identical values
+ *   "jbf_stage_only"     joint bilateral: stage the tile and return WITHOUT WRITING dst
+ *                        (tools/jbf_tune.py --stage-only, timing only)
+ */
+#ifndef REFLECTANCE_FILTERING_DEBUG_H
+#define REFLECTANCE_FILTERING_DEBUG_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Sets option `name` to `value` (>= 0) and returns its previous value; RF_E_BADARG (-1) for an
+ * unknown name. */
+int rf_debug_option(const char *name, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REFLECTANCE_FILTERING_DEBUG_H */

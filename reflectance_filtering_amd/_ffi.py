@@ -25,6 +25,9 @@ EXPORTS = ("rf_version", "rf_last_error", "rf_shutdown", "rf_jbf_u8", "rf_gf_wor
            "rf_colorize_srgb_u8", "rf_whdr_f32", "rf_jbf_f32_workspace_bytes", "rf_jbf_f32",
            "rf_gf_f32_workspace_bytes", "rf_gf_f32")
 
+# include/reflectance_filtering_debug.h: test / benchmark switches, not part of the boundary
+DEBUG_EXPORTS = ("rf_debug_option",)
+
 _lib = None
 _lock = threading.Lock()
 
@@ -78,8 +81,35 @@ def load_library():
         lib.rf_gf_f32.restype = ci
         lib.rf_whdr_f32.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, cd, vp, vp]
         lib.rf_whdr_f32.restype = ci
+        lib.rf_debug_option.argtypes = [ctypes.c_char_p, ci]
+        lib.rf_debug_option.restype = ci
         _lib = lib
         return lib
+
+
+class debug_options:
+    """Context manager around rf_debug_option (include/reflectance_filtering_debug.h):
+    ``with debug_options(gf_two_kernel=1): ...`` selects the alternative kernels that tests and
+    timing tools compare with the default ones, and restores the previous values on exit."""
+
+    def __init__(self, **opts):
+        self.opts = opts
+        self.prev = {}
+
+    def __enter__(self):
+        lib = load_library()
+        for name, value in self.opts.items():
+            old = lib.rf_debug_option(name.encode(), int(value))
+            if old < 0:
+                raise ValueError("unknown debug option %r" % name)
+            self.prev[name] = old
+        return self
+
+    def __exit__(self, *exc):
+        lib = load_library()
+        for name, old in self.prev.items():
+            lib.rf_debug_option(name.encode(), old)
+        return False
 
 
 def check(rc, what):

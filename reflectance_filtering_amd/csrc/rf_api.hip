@@ -1,6 +1,11 @@
 // rf_api.hip -- version, error reporting and shutdown of librf_hip.so.
 #include "rf_common.hpp"
 
+#include <atomic>
+#include <cstring>
+
+#include "reflectance_filtering_debug.h"
+
 namespace rf {
 
 void jbf_shutdown();
@@ -21,7 +26,23 @@ int fail(int code, const char *fmt, ...)
     return code;
 }
 
+static std::atomic<int> g_debug[kDbgCount];
+
+int debug_get(int id) { return g_debug[id].load(std::memory_order_relaxed); }
+
 }  // namespace rf
+
+extern "C" int rf_debug_option(const char *name, int value)
+{
+    static const char *const names[rf::kDbgCount] = {"gf_two_kernel",     "jbf_stage_only",
+                                                      "jbf_compiler_loop", "jbf_tile64_only",
+                                                      "jbf_tune",          "jbf_f32_untiled"};
+    if (name)
+        for (int i = 0; i < rf::kDbgCount; i++)
+            if (std::strcmp(name, names[i]) == 0)
+                return rf::g_debug[i].exchange(value < 0 ? 0 : value);
+    return rf::fail(RF_E_BADARG, "rf_debug_option: unknown option '%s'", name ? name : "(null)");
+}
 
 extern "C" int rf_version(void) { return RF_VERSION; }
 

@@ -62,4 +62,25 @@ __device__ inline uint8_t saturate_u8(float v)
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// Do the byte ranges [a, a + na) and [b, b + nb) intersect?
+inline bool ranges_overlap(const void *a, size_t na, const void *b, size_t nb)
+{
+    const uintptr_t a0 = (uintptr_t)a, b0 = (uintptr_t)b;
+    return a0 < b0 + nb && b0 < a0 + na;
+}
+
+// Test / benchmark switches behind rf_debug_option() (include/reflectance_filtering_debug.h).
+// All zero unless a test or tool sets them; none of them changes the bytes of a result except
+// kDbgJbfStageOnly, which leaves dst unwritten.
+enum DebugOption {
+    kDbgGfTwoKernel = 0,   // guided filter: row-sum / column-sum kernel pair instead of the fused stage 2
+    kDbgJbfStageOnly,      // joint bilateral: stage the tile and return (timing only)
+    kDbgJbfCompilerLoop,   // joint bilateral: compiler-scheduled tap loop instead of the asm one
+    kDbgJbfTile64Only,     // joint bilateral: 64x64 tiles only (no strip tiles)
+    kDbgJbfTune,           // joint bilateral: kernel-variant override (tools/jbf_tune.py), 0 = auto
+    kDbgJbfF32Untiled,     // float joint bilateral: one-thread-per-pixel kernel
+    kDbgCount
+};
+int debug_get(int id);
+
 }  // namespace rf

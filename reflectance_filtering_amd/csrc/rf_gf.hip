@@ -25,6 +25,10 @@
 // that does not apply to their image exit at once.
 #include "rf_common.hpp"
 
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+
 namespace rf {
 namespace {
 
@@ -431,6 +435,316 @@ __global__ __launch_bounds__(64 * 4 * SCN) void gf_colsum_apply_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// stage 2, fused form (radii 45 and 52, the reference's parameter sets): the double row sums
+// never reach HBM.
+//
+//   gf_rowstate_kernel   walks every row of every alpha/beta plane once (one lane per row, the
+//                        same RowSum<float,double> chain as gf_rowsum_kernel) but stores the
+//                        running sum only at every 16th column: states[plane][x/16][row].
+//   gf_colwalk_kernel    one wave owns 16 columns x the 4 planes (alpha_0..2, beta) of one src
+//                        channel and walks down the image in tiles of R rows.  Row phase (lane =
+//                        row): restart the row chain of each plane from the stored state and
+//                        rebuild the tile's R x 16 row sums in LDS.  Column phase (lane = plane x
+//                        column): ColumnSum<double,float> down the tile; the value leaving the
+//                        window, R[y - r], is the value that entered 2r steps earlier in the same
+//                        lane, so it is kept in a register FIFO of 2r doubles (statically indexed:
+//                        the loop body is two tiles of R rows, fully unrolled).  Every four rows
+//                        the four means of a pixel meet in LDS and q = beta + sum alpha_g I_g is
+//                        formed and stored.
+//
+// Every double add happens in the order of the two-kernel form above, so the bytes are the same;
+// HBM traffic of stage 2 drops from  96 (row sums written) + 192 (read as S+ and S-) + 96 (alpha/
+// beta read twice)  to  48 + 96 (alpha/beta read by both kernels, the second read of the walk from
+// L2) bytes per pixel and src channel triple.
+// ------------------------------------------------------------------------------------------
+constexpr int kSB = 16;      // columns per state block and per column-walk wave
+constexpr int kRing = 128;   // padded-row ring of gf_rowstate_kernel; needs 2r + 1 <= 112
+
+// planes: [img][src_np][h][w]; states: [img * np + plane][nb][h], nb = ceil(w / 16);
+// states[..][b][row] = RowSum at column 16 b.  grid: (planes of the chunk) x (64-row blocks).
+__global__ __launch_bounds__(64) void gf_rowstate_kernel(const float *__restrict__ planes,
+                                                         double *__restrict__ states, int h, int w,
+                                                         int radius, int row_blocks, int np,
+                                                         const int *__restrict__ colour, int src_np,
+                                                         int nb)
+{
+    const int plane = blockIdx.x / row_blocks;
+    if (colour != nullptr && plane % np >= 4 && colour[plane / np] == 0)
+        return;  // grey 3-channel images only carry the 4 planes of their first channel
+    __shared__ float ring[kBRows][kRing + 1];
+
+    const int lane = threadIdx.x;
+    const int row0 = (blockIdx.x - plane * row_blocks) * kBRows;
+    const float *S = planes + ((size_t)(plane / np) * src_np + plane % np) * h * w;
+    double *ST = states + (size_t)plane * nb * h;
+    const int ks = 2 * radius + 1;
+    const int total = w + 2 * radius;  // length of the border-extended row
+    const int rr = lane >> 4, cc = lane & 15;
+    const bool row_ok = row0 + lane < h;
+
+    // One wave per workgroup and (33 KB of LDS) one wave per SIMD: nothing but the wave's own
+    // loads in flight hides the HBM latency, so operands are fetched kDepth chunks ahead into
+    // registers (statically rotated: the chunk loop is unrolled by kDepth).
+    constexpr int kDepth = 4;
+    float pre[kDepth][16];
+#define RF_RS_FETCH(slot_, i0_)                                                              \
+    do {                                                                                     \
+        const int sx_ = border_interpolate(min((i0_) + cc, total - 1) - radius, w,           \
+                                           RF_BORDER_REFLECT);                               \
+        _Pragma("unroll") for (int k = 0; k < 16; k++)                                       \
+        {                                                                                    \
+            const int row_ = min(row0 + 4 * k + rr, h - 1);                                  \
+            pre[slot_][k] = S[(size_t)row_ * w + sx_];                                       \
+        }                                                                                    \
+    } while (0)
+    const int cstore = (ks - 1) & 15;  // chunk position after which s is a state (o % 16 == 0)
+    double s = 0.0;
+    // one chunk: registers -> ring, refill the slot with the chunk kDepth ahead, run the chain
+#define RF_RS_CHUNK(slot_, i0_)                                                              \
+    do {                                                                                     \
+        const int i0c_ = (i0_);                                                              \
+        if (i0c_ < total) {                                                                  \
+            _Pragma("unroll") for (int k = 0; k < 16; k++)                                   \
+                ring[4 * k + rr][(i0c_ + cc) & (kRing - 1)] = pre[slot_][k];                 \
+            __syncthreads();                                                                 \
+            if (i0c_ + 16 * kDepth < total)                                                  \
+                RF_RS_FETCH(slot_, i0c_ + 16 * kDepth);                                      \
+            if (i0c_ + 16 <= ks - 1) { /* s = ext[0] + ... sequentially from the left end */ \
+                _Pragma("unroll") for (int c = 0; c < 16; c++)                               \
+                    s += (double)ring[lane][(i0c_ + c) & (kRing - 1)];                       \
+            } else if (i0c_ >= ks && i0c_ + 16 <= total) {                                   \
+                _Pragma("unroll") for (int c = 0; c < 16; c++)                               \
+                {                                                                            \
+                    const float e_ = ring[lane][(i0c_ + c) & (kRing - 1)];                   \
+                    const float l_ = ring[lane][(i0c_ + c - ks) & (kRing - 1)];              \
+                    s += (double)e_ - (double)l_;                                            \
+                    if (c == cstore && row_ok)                                               \
+                        ST[(size_t)((i0c_ + c - ks + 1) >> 4) * h + row0 + lane] = s;        \
+                }                                                                            \
+            } else {                                                                         \
+                const int cnt_ = min(16, total - i0c_);                                      \
+                for (int c = 0; c < cnt_; c++) {                                             \
+                    const int i = i0c_ + c;                                                  \
+                    const float e_ = ring[lane][i & (kRing - 1)];                            \
+                    if (i < ks) {                                                            \
+                        s += (double)e_;                                                     \
+                    } else {                                                                 \
+                        const float l_ = ring[lane][(i - ks) & (kRing - 1)];                 \
+                        s += (double)e_ - (double)l_;                                        \
+                    }                                                                        \
+                    const int o = i - ks + 1; /* output column whose RowSum s now is */      \
+                    if (o >= 0 && (o & (kSB - 1)) == 0 && row_ok)                            \
+                        ST[(size_t)(o >> 4) * h + row0 + lane] = s;                          \
+                }                                                                            \
+            }                                                                                \
+        }                                                                                    \
+    } while (0)
+    RF_RS_FETCH(0, 0);
+    RF_RS_FETCH(1, 16);
+    RF_RS_FETCH(2, 32);
+    RF_RS_FETCH(3, 48);
+    for (int i0 = 0; i0 < total; i0 += 16 * kDepth) {
+        RF_RS_CHUNK(0, i0);
+        RF_RS_CHUNK(1, i0 + 16);
+        RF_RS_CHUNK(2, i0 + 32);
+        RF_RS_CHUNK(3, i0 + 48);
+    }
+#undef RF_RS_CHUNK
+#undef RF_RS_FETCH
+}
+
+// grid: 8 * ceil(items / 8) single-wave workgroups; items = images x SCN x nb, walked so that each
+// XCD (workgroup id mod 8) owns a contiguous run of column blocks: a block's "leaving" operands
+// are the "entering" operands of the block ~1.4 places to its left, served by that XCD's L2.
+//
+// The walk advances in sub-tiles of T padded rows (2R = NSUB * T; T = 15 for R = 45, 13 for 52):
+//   row phase     lane = (plane, row): 4 x T chains of 15 steps from the stored states -> Rt (LDS)
+//   column phase  lane = (plane, column): T steps of ColumnSum<double,float>; FIFO slot of step jj
+//                 of the k-th sub-tile of a period = k T + jj (the period loop is unrolled)
+//   flush         the T x 16 finished pixels: q = beta + a0 I0 + a1 I1 + a2 I2 -> uint8
+// One wave per workgroup: no s_barrier anywhere (__syncthreads() is the LDS fence of the wave).
+// The wave hides memory latency itself: operands and states of sub-tile u+1 and the guide bytes of
+// sub-tile u are requested before sub-tile u's chains run.
+template <int R, int T, int SCN, int SPX>
+__global__ __launch_bounds__(64) void gf_colwalk_kernel(
+    const float *__restrict__ ab, const double *__restrict__ states,
+    const uint8_t *__restrict__ guide, uint8_t *__restrict__ dst, int h, int w, int nb,
+    int n_items, const int *__restrict__ colour)
+{
+    constexpr int KS = 2 * R + 1;
+    constexpr int NSUB = 2 * R / T;
+    static_assert(NSUB * T == 2 * R && 4 * T <= 64 && (T & 1), "sub-tile height");
+    constexpr int NG = (T * 12 + 63) / 64;  // guide dwords per lane and sub-tile
+    constexpr int NF = (T * kSB + 63) / 64; // flush pixels per lane and sub-tile
+    const int per_xcd = (n_items + 7) >> 3;
+    const int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || item >= n_items)
+        return;
+    const int b = item % nb;
+    const int s_ch = (item / nb) % SCN;
+    const int img = item / (nb * SCN);
+    if (wrong_variant<SCN>(colour, img))
+        return;
+
+    __shared__ double Rt[64][T];                              // row sums [plane*16 + col][row]
+    __shared__ float stE[4 * T][kSB + 1], stL[4 * T][kSB + 1]; // operands [plane*T + row][col]
+    __shared__ float xch[T][4][kSB];                          // means of the sub-tile's rows
+    __shared__ int rowtab[2][T + 1];                          // image row of each padded row
+    __shared__ uint32_t gst[T][12];                           // guide bytes of the output rows
+
+    const int lane = threadIdx.x;
+    const int g4 = lane >> 4, cc = lane & 15;  // loader and column role: plane, column
+    const int cp = lane / T, cl = lane - cp * T;  // chain role (lane < 4T): plane, row
+    const bool chain = lane < 4 * T;
+    const size_t npx = (size_t)h * w;
+    constexpr int np = 4 * SPX;
+    const float *abg = ab + ((size_t)img * np + 4 * s_ch) * npx;          // planes 4s .. 4s+3
+    const double *stg = states + ((size_t)img * np + 4 * s_ch) * nb * h;  // their states
+    const uint8_t *gimg = guide + (size_t)img * npx * 3;
+    uint8_t *dimg = dst + (size_t)img * npx * SPX;
+    // RowSum at output column o = 16 b + cc (cc >= 1):  + ext[o + 2r] - ext[o - 1], ext[i] = S[bi(i - r)]
+    const float *Pe = abg + (size_t)g4 * npx + border_interpolate(b * kSB + cc + R, w, RF_BORDER_REFLECT);
+    const float *Pl = abg + (size_t)g4 * npx + border_interpolate(b * kSB + cc - 1 - R, w, RF_BORDER_REFLECT);
+    const double *Ps = stg + ((size_t)min(cp, 3) * nb + b) * h;
+    const double scale = 1.0 / (double)(KS * KS);
+    const int nsub = (h + 2 * R + T - 1) / T;  // > NSUB
+    const int jmax = h + 2 * R - 1;
+    const uint32_t gbytes = (uint32_t)(npx * 3);
+
+    float pe[T], pl[T];
+    double pst = 0.0;
+    uint32_t gpre[NG];
+    /* padded row -> image row (BORDER_REFLECT) */
+#define RF_ROWTAB(u_)                                                                        \
+    do {                                                                                     \
+        if (lane < T)                                                                        \
+            rowtab[(u_) & 1][lane] = border_interpolate(min((u_) * T + lane, jmax) - R, h,   \
+                                                        RF_BORDER_REFLECT);                  \
+    } while (0)
+#define RF_FETCH(u_)                                                                         \
+    do {                                                                                     \
+        _Pragma("unroll") for (int L = 0; L < T; L++)                                        \
+        {                                                                                    \
+            const uint32_t ro_ = (uint32_t)rowtab[(u_) & 1][L] * (uint32_t)w;                \
+            pe[L] = Pe[ro_];                                                                 \
+            pl[L] = Pl[ro_];                                                                 \
+        }                                                                                    \
+        if (chain)                                                                           \
+            pst = Ps[rowtab[(u_) & 1][cl]];                                                  \
+    } while (0)
+    /* guide bytes of output rows y0 .. y0+T-1, 48 contiguous bytes per row */
+#define RF_GUIDE_FETCH(y0_)                                                                  \
+    do {                                                                                     \
+        _Pragma("unroll") for (int k = 0; k < NG; k++)                                       \
+        {                                                                                    \
+            const int idx_ = lane + 64 * k;                                                  \
+            const int gy_ = min((y0_) + idx_ / 12, h - 1);                                   \
+            const uint32_t off_ = ((uint32_t)gy_ * w + b * kSB) * 3 + (idx_ % 12) * 4;       \
+            uint32_t v_ = 0;                                                                 \
+            if (off_ + 4 <= gbytes) {                                                        \
+                __builtin_memcpy(&v_, gimg + off_, 4);                                       \
+            } else {                                                                         \
+                for (int q = 0; q < 4; q++)                                                  \
+                    if (off_ + q < gbytes)                                                   \
+                        v_ |= (uint32_t)gimg[off_ + q] << (8 * q);                           \
+            }                                                                                \
+            gpre[k] = v_;                                                                    \
+        }                                                                                    \
+    } while (0)
+
+    double SUM = 0.0;
+    double fifo[2 * R];  // R[y - r] is what entered 2r steps ago: slot = step mod 2r, all static
+    // one sub-tile; KSLOT = its place in the FIFO period, FILL = prologue (padded rows -r .. r-1)
+#define RF_SUB(KSLOT, FILL, u_)                                                              \
+    do {                                                                                     \
+        const int uu_ = (u_);                                                                \
+        RF_ROWTAB(uu_ + 1);                                                                  \
+        _Pragma("unroll") for (int L = 0; L < T; L++)                                        \
+        {                                                                                    \
+            stE[g4 * T + L][cc] = pe[L];                                                     \
+            stL[g4 * T + L][cc] = pl[L];                                                     \
+        }                                                                                    \
+        double s_ = pst;                                                                     \
+        __syncthreads();                                                                     \
+        if (!(FILL))                                                                         \
+            RF_GUIDE_FETCH((uu_ - NSUB) * T);                                                \
+        if (uu_ + 1 < nsub)                                                                  \
+            RF_FETCH(uu_ + 1);                                                               \
+        if (chain) {                                                                         \
+            Rt[cp * kSB][cl] = s_;                                                           \
+            _Pragma("unroll") for (int c = 1; c < kSB; c++)                                  \
+            {                                                                                \
+                s_ += (double)stE[lane][c] - (double)stL[lane][c];                           \
+                Rt[cp * kSB + c][cl] = s_;                                                   \
+            }                                                                                \
+        }                                                                                    \
+        __syncthreads();                                                                     \
+        _Pragma("unroll") for (int jj = 0; jj < T; jj++)                                     \
+        {                                                                                    \
+            const double v_ = Rt[lane][jj];                                                  \
+            if (FILL) {                                                                      \
+                SUM += v_;                                                                   \
+            } else {                                                                         \
+                const double s0_ = SUM + v_;                                                 \
+                xch[jj][g4][cc] = (float)(s0_ * scale);                                      \
+                SUM = s0_ - fifo[(KSLOT) * T + jj];                                          \
+            }                                                                                \
+            fifo[(KSLOT) * T + jj] = v_;                                                     \
+        }                                                                                    \
+        if (!(FILL)) {                                                                       \
+            _Pragma("unroll") for (int k = 0; k < NG; k++)                                   \
+            {                                                                                \
+                const int idx_ = lane + 64 * k;                                              \
+                if (idx_ < T * 12)                                                           \
+                    gst[idx_ / 12][idx_ % 12] = gpre[k];                                     \
+            }                                                                                \
+            __syncthreads();                                                                 \
+            const int y0_ = (uu_ - NSUB) * T;                                                \
+            _Pragma("unroll") for (int k = 0; k < NF; k++)                                   \
+            {                                                                                \
+                const int idx_ = lane + 64 * k;                                              \
+                const int fr_ = idx_ >> 4;                                                   \
+                const int y_ = y0_ + fr_, x_ = b * kSB + cc;                                 \
+                if (fr_ < T && y_ < h && x_ < w) {                                           \
+                    const uint32_t pix_ = (uint32_t)y_ * w + x_;                             \
+                    const uint8_t *gb_ = reinterpret_cast<const uint8_t *>(&gst[fr_][0]) + 3 * cc; \
+                    float q_ = xch[fr_][3][cc];                                              \
+                    q_ = __fadd_rn(q_, __fmul_rn(xch[fr_][0][cc], (float)gb_[0]));           \
+                    q_ = __fadd_rn(q_, __fmul_rn(xch[fr_][1][cc], (float)gb_[1]));           \
+                    q_ = __fadd_rn(q_, __fmul_rn(xch[fr_][2][cc], (float)gb_[2]));           \
+                    const uint8_t o_ = saturate_u8(q_);                                      \
+                    if (SCN == SPX) {                                                        \
+                        dimg[(size_t)pix_ * SCN + s_ch] = o_;                                \
+                    } else { /* grey image: the computed channel stands for all three */     \
+                        dimg[(size_t)pix_ * 3 + 0] = o_;                                     \
+                        dimg[(size_t)pix_ * 3 + 1] = o_;                                     \
+                        dimg[(size_t)pix_ * 3 + 2] = o_;                                     \
+                    }                                                                        \
+                }                                                                            \
+            }                                                                                \
+            __syncthreads();                                                                 \
+        }                                                                                    \
+    } while (0)
+
+    RF_ROWTAB(0);
+    __syncthreads();
+    RF_FETCH(0);
+#pragma unroll
+    for (int k = 0; k < NSUB; k++)
+        RF_SUB(k, true, k);
+    for (int u0 = NSUB; u0 < nsub; u0 += NSUB) {
+#pragma unroll
+        for (int k = 0; k < NSUB; k++)
+            if (u0 + k < nsub)
+                RF_SUB(k, false, u0 + k);
+    }
+#undef RF_SUB
+#undef RF_GUIDE_FETCH
+#undef RF_FETCH
+#undef RF_ROWTAB
+}
+
+// ------------------------------------------------------------------------------------------
 // CV_32F variant.  Same operations as the uint8 path, but the stage-1 window
 // sums are no longer exact integers, so every box filter is the order-faithful pair
 // RowSum<float,double> / ColumnSum<double,float>: products -> row sums -> column sums -> means
@@ -586,8 +900,13 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
     // uint32 window sums: (2r+1)^2 * 255^2 must stay below 2^32; strip width must hold the halo
     if (radius < 0 || radius > 120)
         return fail(RF_E_UNSUPPORTED, "rf_gf_u8: radius %d outside 0..120", radius);
-    if (dst == guide)
-        return fail(RF_E_BADARG, "rf_gf_u8: dst must not alias guide");
+    {
+        const size_t px = (size_t)n * h * w;
+        if (ranges_overlap(dst, px * src_cn, guide, px * 3))
+            return fail(RF_E_BADARG, "rf_gf_u8: dst must not overlap guide");
+        if (dst != src && ranges_overlap(dst, px * src_cn, src, px * src_cn))
+            return fail(RF_E_BADARG, "rf_gf_u8: dst may equal src but not partially overlap it");
+    }
     if (n == 0)
         return RF_OK;
     const int np = 4 * src_cn;
@@ -598,9 +917,15 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
         return fail(RF_E_WORKSPACE, "rf_gf_u8: workspace %zu B < %zu B needed for one image",
                     workspace_bytes, header + per_img);
     hipStream_t stream = (hipStream_t)stream_;
-    int chunk = (int)std::min<size_t>((size_t)n, (workspace_bytes - header) / per_img);
-    if (chunk > 65535)
-        chunk = 65535;
+    // fused stage 2 (row states + column walk) for the instantiated radii; the debug option
+    // "gf_two_kernel" forces the row-sum / column-sum kernel pair (cross-check of tests and tools)
+    const bool fused = !debug_get(kDbgGfTwoKernel) && (radius == 45 || radius == 52);
+    const int nb = ceil_div(w, kSB);
+    const size_t per_img_fused = (size_t)np * (npx * sizeof(float) + (size_t)nb * h * sizeof(double));
+    const size_t per_img_used = fused ? per_img_fused : per_img;
+    int chunk = (int)std::min<size_t>((size_t)n, (workspace_bytes - header) / per_img_used);
+    if (chunk > 16383)
+        chunk = 16383;
     const float eps_f = (float)eps;
     const int eps_small = eps < 1e-2;
     const int out_w = kACW - 2 * radius;
@@ -622,8 +947,10 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
     for (int i0 = 0; i0 < n; i0 += chunk) {
         const int m = std::min(chunk, n - i0);
         const int *colour = colour_all ? colour_all + i0 : nullptr;
+        // two-kernel form: [row sums (double)][alpha/beta]; fused form: [states (double)][alpha/beta]
         double *rows = reinterpret_cast<double *>(static_cast<char *>(workspace) + header);
-        float *ab = reinterpret_cast<float *>(rows + (size_t)m * np * npx);
+        float *ab = reinterpret_cast<float *>(rows + (fused ? (size_t)m * np * nb * h
+                                                            : (size_t)m * np * npx));
         const uint8_t *g0 = guide + (size_t)i0 * npx * 3;
         uint8_t *d0 = dst + (size_t)i0 * npx * src_cn;
         // row segments: enough workgroups to fill 256 CUs, but segments no shorter than 2r+1
@@ -645,6 +972,30 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
                                    ab, h, w, radius, eps_f, eps_small, seg_rows, colour);
             }
             const int row_blocks = ceil_div(h, kBRows);
+            if (fused) {
+                hipLaunchKernelGGL(gf_rowstate_kernel, dim3((unsigned)(m * np * row_blocks)), dim3(64),
+                                   0, stream, ab, rows, h, w, radius, row_blocks, np, colour, np, nb);
+                const int it3 = m * 3 * nb, it1 = m * nb;
+                const dim3 g3(8 * (unsigned)ceil_div(it3, 8)), g1(8 * (unsigned)ceil_div(it1, 8));
+#define RF_GF_WALK(R, TT)                                                                             \
+    do {                                                                                           \
+        if (src_cn == 3) {                                                                         \
+            hipLaunchKernelGGL((gf_colwalk_kernel<R, TT, 3, 3>), g3, dim3(64), 0, stream, ab, rows, g0, \
+                               d0, h, w, nb, it3, colour);                                         \
+            hipLaunchKernelGGL((gf_colwalk_kernel<R, TT, 1, 3>), g1, dim3(64), 0, stream, ab, rows, g0, \
+                               d0, h, w, nb, it1, colour);                                         \
+        } else {                                                                                   \
+            hipLaunchKernelGGL((gf_colwalk_kernel<R, TT, 1, 1>), g1, dim3(64), 0, stream, ab, rows, g0, \
+                               d0, h, w, nb, it1, colour);                                         \
+        }                                                                                          \
+    } while (0)
+                if (radius == 45)
+                    RF_GF_WALK(45, 15);
+                else
+                    RF_GF_WALK(52, 13);
+#undef RF_GF_WALK
+                continue;
+            }
             hipLaunchKernelGGL(gf_rowsum_kernel, dim3((unsigned)(m * np * row_blocks)), dim3(64), 0,
                                stream, ab, rows, h, w, radius, row_blocks, np, colour, np);
             dim3 gc(ceil_div(w, 64), 1, m);
@@ -698,8 +1049,13 @@ extern "C" int rf_gf_f32(const float *guide, const float *src, float *dst, int n
         return fail(RF_E_UNSUPPORTED, "rf_gf_f32: src channels must be 1 or 3 (got %d)", src_cn);
     if (radius < 0 || radius > 4096)
         return fail(RF_E_UNSUPPORTED, "rf_gf_f32: radius %d outside 0..4096", radius);
-    if (dst == guide)
-        return fail(RF_E_BADARG, "rf_gf_f32: dst must not alias guide");
+    {
+        const size_t px = (size_t)n * h * w * sizeof(float);
+        if (ranges_overlap(dst, px * src_cn, guide, px * 3))
+            return fail(RF_E_BADARG, "rf_gf_f32: dst must not overlap guide");
+        if (dst != src && ranges_overlap(dst, px * src_cn, src, px * src_cn))
+            return fail(RF_E_BADARG, "rf_gf_f32: dst may equal src but not partially overlap it");
+    }
     const int nq = 9 + 4 * src_cn;
     const size_t npx = (size_t)h * w;
     const size_t per_img = npx * nq * (sizeof(float) + sizeof(double));

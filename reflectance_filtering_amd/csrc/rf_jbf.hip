@@ -33,6 +33,9 @@ constexpr int kTileW = 64;
 constexpr int kPix = 4;        // outputs per lane (horizontal)
 constexpr int kMaxLds = 160 * 1024;
 constexpr int kTlw2 = 144;     // tile row pitch in texels of jbf_tiled2_kernel (radius <= 36)
+// private flag bits above the public RF_JBF_* ones: the test / benchmark switches of
+// rf_debug_option() as the kernels see them
+constexpr int kJbfStageOnly = 0x1000, kJbfCompilerLoop = 0x2000, kJbfTile64Only = 0x4000;
 
 typedef uint32_t uint2v __attribute__((ext_vector_type(2)));
 typedef float float4v __attribute__((ext_vector_type(4)));
@@ -846,7 +849,7 @@ __global__ __launch_bounds__(16 * TH) void jbf_tiled2_kernel(
         }
     }
     const int all_grey = block_all(grey, flag_word);  // also the barrier that publishes the tile
-    if (flags & 0x1000)  // benchmark aid: staging only (tools/jbf_tune.py --stage-only)
+    if (flags & kJbfStageOnly)  // benchmark aid: staging only (tools/jbf_tune.py --stage-only)
         return;
 
     const int tx = tid & 15;
@@ -967,7 +970,7 @@ __global__ __launch_bounds__(1024) void jbf_tile64_kernel(
     // the SAD of the tap loop into the gather address (jbf_tap_loop_grey4<.., J1 = true>).
     // Known up front for 1-channel buffers (j1): staged in that form.  For 3-channel buffers
     // it is found out per tile, and the staged tile is then rewritten in LDS.
-    const bool j1_ok = !(flags & 0x2000);
+    const bool j1_ok = !(flags & kJbfCompilerLoop);
     const bool j1 = SCN == 1 && jcn != 3 && j1_ok;
     const uint32_t j1_scale = (uint32_t)(jcn == 1 ? 1 : 3) * (GREP * 4u);
     const int tlh = TH + 2 * radius;
@@ -990,7 +993,7 @@ __global__ __launch_bounds__(1024) void jbf_tile64_kernel(
     // (the barrier inside also publishes sw table, LUT and tile)
     const int grey_bits = block_all2(grey, grey_joint, const_cast<int *>(flag_word));
     const int all_grey = grey_bits & 1;
-    if (flags & 0x1000)  // benchmark aid: staging only (tools/jbf_tune.py --stage-only)
+    if (flags & kJbfStageOnly)  // benchmark aid: staging only (tools/jbf_tune.py --stage-only)
         return;
     // grey src and grey joint found out only now: rewrite the joint fields in place
     const bool j1_late = !j1 && j1_ok && (SCN == 1 || all_grey) && (grey_bits & 2);
@@ -1018,7 +1021,7 @@ __global__ __launch_bounds__(1024) void jbf_tile64_kernel(
         }
         const uint32_t lut_lane_addr = lds_addr(lut_g) + (uint32_t)(tid & (GREP - 1)) * 4u;
         const uint32_t tile_lane_addr = lds_addr(tile4) + (uint32_t)tx * 4u;
-        if (flags & 0x2000)  // benchmark aid: compiler-scheduled loop instead of the asm one
+        if (flags & kJbfCompilerLoop)  // benchmark aid: compiler-scheduled loop instead of the asm one
             jbf_tap_loop<1, GREP, false, TLW, 4>(lut_lane_addr, sw_addr0, tile_lane_addr, 0u, jc, 0u,
                                                  ty, radius, r4, sw_len, hwtab, sum1, wsum);
         else if (j1 || j1_late)
@@ -1266,7 +1269,7 @@ int launch_tile64_rows(const JbfTables &t, int nz, int crows, const uint8_t *joi
                        const uint8_t *src, uint8_t *dst, int n, int h, int w, int jcn, int border,
                        int flags, hipStream_t stream)
 {
-    const bool only64 = (flags & 0x4000) != 0;  // benchmark / test aid: 64x64 tiles only
+    const bool only64 = (flags & kJbfTile64Only) != 0;  // benchmark / test aid: 64x64 tiles only
     // ---- right strip (single-channel sources)
     int sx = 0;
     if (SCN == 1 && !only64 && (w & 63) > 0 && (w & 63) <= 32 &&
@@ -1437,10 +1440,18 @@ extern "C" int rf_jbf_u8(const uint8_t *joint, const uint8_t *src, uint8_t *dst,
                     joint_cn, src_cn);
     if (border < 0 || border > 4)
         return fail(RF_E_UNSUPPORTED, "rf_jbf_u8: border type %d", border);
-    if (dst == joint || dst == src)
-        return fail(RF_E_BADARG, "rf_jbf_u8: dst must not alias an input");
-    if (n == 0)
-        return RF_OK;
+    {
+        const size_t px = (size_t)n * h * w;
+        if (ranges_overlap(dst, px * src_cn, joint, px * joint_cn) ||
+            ranges_overlap(dst, px * src_cn, src, px * src_cn))
+            return fail(RF_E_BADARG, "rf_jbf_u8: dst must not overlap an input");
+    }
+    if (flags & ~(RF_JBF_TRUE_DIVISION | RF_JBF_FORCE_GENERIC | RF_JBF_GREY_AS_BGR))
+        return fail(RF_E_BADARG, "rf_jbf_u8: unknown flag bits 0x%x", flags);
+    // test / benchmark switches (rf_debug_option) travel to the kernels as private flag bits
+    flags |= (debug_get(kDbgJbfStageOnly) ? kJbfStageOnly : 0) |
+             (debug_get(kDbgJbfCompilerLoop) ? kJbfCompilerLoop : 0) |
+             (debug_get(kDbgJbfTile64Only) ? kJbfTile64Only : 0);
     // OpenCV: non-positive sigmas become 1; radius from d or from sigma_space
     if (sigma_color <= 0)
         sigma_color = 1;
@@ -1466,7 +1477,7 @@ extern "C" int rf_jbf_u8(const uint8_t *joint, const uint8_t *src, uint8_t *dst,
     // ---- kernel selection -------------------------------------------------------------
     // tune = 0: automatic; 1..6 force a (tile height, LUT replicas, full LUT) configuration of
     // the tiled kernel (benchmark aid, tools/jbf_tune.py).
-    const int tune = (flags >> RF_JBF_TUNE_SHIFT) & 0xf;
+    const int tune = debug_get(kDbgJbfTune) & 0xf;
     static const Tiled2Config kCfg[] = {{48, 16, false}, {32, 8, true},  {32, 32, false},
                                         {32, 16, false}, {64, 16, false}, {48, 8, false}};
     constexpr int kNumCfg = (int)(sizeof(kCfg) / sizeof(kCfg[0]));
@@ -1580,8 +1591,12 @@ extern "C" int rf_jbf_f32(const float *joint, const float *src, float *dst, int 
     // 32F code indexes its table out of bounds there (undefined); not offered
     if (border < 1 || border > 4)
         return fail(RF_E_UNSUPPORTED, "rf_jbf_f32: border type %d", border);
-    if (dst == joint || dst == src)
-        return fail(RF_E_BADARG, "rf_jbf_f32: dst must not alias an input");
+    {
+        const size_t px = (size_t)n * h * w * sizeof(float);
+        if (ranges_overlap(dst, px * src_cn, joint, px * joint_cn) ||
+            ranges_overlap(dst, px * src_cn, src, px * src_cn))
+            return fail(RF_E_BADARG, "rf_jbf_f32: dst must not overlap an input");
+    }
     if (n > 65535)
         return fail(RF_E_UNSUPPORTED, "rf_jbf_f32: n <= 65535 per call");
     if (workspace_bytes < rf_jbf_f32_workspace_bytes(n, joint_cn))

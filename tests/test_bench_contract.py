@@ -23,3 +23,47 @@ def test_valu_roofline_object():
     per_wave = obj["column_steps_per_launch"] / (256 * 30 * 17 * 16)
     assert 3409 / 4 < per_wave < 67 * (67 + 11) / 1 and per_wave % 4 == 0
     assert np.isclose(obj["taps_per_s"], taps / 0.265)
+
+
+def _run_bench(extra_args, env_extra, timeout=300):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RF_BENCH_STUB="1", **env_extra)
+    for key in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        if key not in env_extra:
+            env.pop(key, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra_args, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    return p.returncode, (json.loads(lines[-1]) if lines else None), p.stderr.decode()
+
+
+def test_bench_launches_its_own_ranks_and_sums_their_pixels():
+    """`python bench.py --gpus 2` starts two ranks itself (gloo here, kernel call stubbed): one
+    JSON line from rank 0 with n_gpus = 2 and the pixels of both ranks in `value`."""
+    rc, out, err = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4",
+                               "--height", "8", "--width", "16"], {})
+    assert rc == 0, err[-2000:]
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1
+    assert out["scaling"] == "weak" and out["higher_is_better"] is True
+    assert out["config"]["batch_per_gpu"] == 4
+    job_px = 2 * 4 * 8 * 16 * 3                       # ranks x batch x h x w x steps
+    assert np.isclose(out["value"] * 1e6 * out["ms_per_step"] * 1e-3 * 3, job_px, rtol=1e-6)
+    assert out["ms_per_step"] >= 10.0                 # the stub step sleeps 10 ms
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    rc, out, err = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"],
+                              {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert rc != 0 and out is None
+    assert "WORLD_SIZE" in err
+
+
+def test_bench_configs_name_the_baseline_shapes():
+    assert bench.CONFIGS["c4"] == ("jbf", 512, 1080, 1920)       # 4096 images over 8 GPUs
+    assert bench.CONFIGS["c5"] == ("gf3", 128, 2160, 3840)       # 1024 images over 8 GPUs
+    assert bench.CONFIGS["c3"] == ("chain", 256, 333, 500)
+    assert bench.CONFIGS["north_star"] == ("jbf", 256, 1080, 1920)

@@ -13,8 +13,8 @@ from reflectance_filtering_amd import _ffi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _header_functions():
-    with open(os.path.join(ROOT, "include", "reflectance_filtering.h")) as fh:
+def _header_functions(name="reflectance_filtering.h"):
+    with open(os.path.join(ROOT, "include", name)) as fh:
         text = re.sub(r"/\*.*?\*/", "", fh.read(), flags=re.S)
     return sorted(set(re.findall(r"\b(rf_[a-z0-9_]+)\s*\(", text)))
 
@@ -29,6 +29,13 @@ def test_library_exports_every_declared_symbol(built):
     out = subprocess.check_output(["nm", "-D", "--defined-only", _ffi.LIB_PATH]).decode()
     for name in names:
         assert re.search(r"\bT %s\b" % name, out), name
+    # the test / benchmark switches are declared in their own header, outside the boundary
+    dbg = _header_functions("reflectance_filtering_debug.h")
+    assert set(dbg) == set(_ffi.DEBUG_EXPORTS)
+    for name in dbg:
+        assert re.search(r"\bT %s\b" % name, out), name
+    exported = set(re.findall(r"\bT (rf_[a-z0-9_]+)\b", out))
+    assert exported == set(names) | set(dbg), exported ^ (set(names) | set(dbg))
 
 
 def test_code_object_is_gfx950_only(built, tmp_path):
@@ -79,13 +86,27 @@ def test_no_packed_f32_op_sel_on_scalar_operands(built, tmp_path):
 
 def test_argument_validation_needs_no_gpu(built):
     lib = _ffi.load_library()
-    bufs = [ctypes.create_string_buffer(64) for _ in range(3)]
+    bufs = [ctypes.create_string_buffer(64 * 64 * 3) for _ in range(3)]
     p, q, o = (ctypes.cast(b, ctypes.c_void_p) for b in bufs)
     assert lib.rf_jbf_u8(None, q, o, 1, 4, 4, 3, 3, -1, 20.0, 22.0, 4, 0, None) == _ffi.RF_E_BADARG
     assert b"NULL" in lib.rf_last_error()
     assert lib.rf_jbf_u8(p, q, o, 1, 4, 4, 2, 3, -1, 20.0, 22.0, 4, 0, None) == _ffi.RF_E_UNSUPPORTED
     assert lib.rf_jbf_u8(p, q, o, 1, 0, 4, 3, 3, -1, 20.0, 22.0, 4, 0, None) == _ffi.RF_E_BADARG
     assert lib.rf_jbf_u8(p, q, o, 1, 4, 4, 3, 3, -1, 20.0, 22.0, 9, 0, None) == _ffi.RF_E_UNSUPPORTED
+    # undocumented flag bits are rejected (the old benchmark bits moved behind rf_debug_option)
+    assert lib.rf_jbf_u8(p, q, o, 1, 4, 4, 3, 3, -1, 20.0, 22.0, 4, 0x1000, None) == _ffi.RF_E_BADARG
+    assert b"flag" in lib.rf_last_error()
+    # overlap is checked by range, not by pointer equality
+    big = ctypes.create_string_buffer(256)
+    base = ctypes.cast(big, ctypes.c_void_p).value
+    assert lib.rf_jbf_u8(base, base + 128, base + 140, 1, 4, 4, 3, 3, -1, 20.0, 22.0, 4, 0,
+                         None) == _ffi.RF_E_BADARG
+    assert b"overlap" in lib.rf_last_error()
+    assert lib.rf_gf_u8(base, base + 64, base + 80, 1, 4, 4, 3, 3, 2, 1.0, 1, p, 1 << 20,
+                        None) == _ffi.RF_E_BADARG
+    assert lib.rf_debug_option(b"no_such_option", 1) == _ffi.RF_E_BADARG
+    assert lib.rf_debug_option(b"gf_two_kernel", 1) == 0
+    assert lib.rf_debug_option(b"gf_two_kernel", 0) == 1
     assert lib.rf_gf_u8(p, q, o, 1, 4, 4, 1, 3, 2, 1.0, 1, p, 1 << 20, None) == _ffi.RF_E_UNSUPPORTED
     assert lib.rf_gf_u8(p, q, o, 1, 4, 4, 3, 3, 2, 1.0, 0, p, 1 << 20, None) == _ffi.RF_E_BADARG
     assert lib.rf_gf_u8(p, q, o, 1, 4, 4, 3, 3, 500, 1.0, 1, p, 1 << 20, None) == _ffi.RF_E_UNSUPPORTED

@@ -186,7 +186,7 @@ def test_jbf_randomised_sweep(env):
 @pytest.mark.parametrize("sc,ss", [(20.0, 22.0), (15.0, 28.0), (9.0, 5.0), (30.0, 23.7)])
 def test_jbf_row_pipeline(env, sc, ss):
     """The grey tap loop carries its software pipeline from one tap row into the next (the last
-    group of a row prefetches the next row); against the compiler-scheduled loop (0x2000), the
+    group of a row prefetches the next row); against the compiler-scheduled loop (debug option), the
     64x64-only launch and the oracle, for several radii (different row shapes)."""
     from tests import synth
     rf, co, torch = env
@@ -196,8 +196,9 @@ def test_jbf_row_pipeline(env, sc, ss):
     jd, sd = _dev(torch, joint, grey)
     got = rf.ops.joint_bilateral_u8(jd, sd, -1, sc, ss)
     assert np.array_equal(got.cpu().numpy()[0], co.joint_bilateral_filter(joint, grey, -1, sc, ss))
-    for flags in (0x2000, 0x4000):
-        assert torch.equal(rf.ops.joint_bilateral_u8(jd, sd, -1, sc, ss, flags=flags), got), flags
+    for opt in ("jbf_compiler_loop", "jbf_tile64_only"):
+        with rf._ffi.debug_options(**{opt: 1}):
+            assert torch.equal(rf.ops.joint_bilateral_u8(jd, sd, -1, sc, ss), got), opt
 
 
 def test_jbf_grey_joint_detected_at_run_time(env):
@@ -220,13 +221,14 @@ def test_jbf_grey_joint_detected_at_run_time(env):
         got = rf.ops.joint_bilateral_u8(jd, sd, -1, 20.0, 22.0).cpu().numpy()[0]
         want = co.joint_bilateral_filter(joint, src, -1, 20.0, 22.0)
         assert np.array_equal(got, want.reshape(got.shape)), (joint.shape, src.shape)
-        assert torch.equal(rf.ops.joint_bilateral_u8(jd, sd, -1, 20.0, 22.0, flags=0x2000).cpu(),
-                           torch.from_numpy(got[None]))
+        with rf._ffi.debug_options(jbf_compiler_loop=1):
+            assert torch.equal(rf.ops.joint_bilateral_u8(jd, sd, -1, 20.0, 22.0).cpu(),
+                               torch.from_numpy(got[None]))
 
 
 def test_jbf_strip_tiles(env):
     """Single-channel sources finish the last h % 64 rows with 32x128 / 16x256 tiles; every
-    remainder class must match the oracle and the 64x64-only launch (flag 0x4000)."""
+    remainder class must match the oracle and the 64x64-only launch (debug option jbf_tile64_only)."""
     from tests import synth
     rf, co, torch = env
     w = 300
@@ -239,8 +241,8 @@ def test_jbf_strip_tiles(env):
             j3 = jt if jt.shape[2] == 3 else np.repeat(jt, 3, axis=2)
             want = co.joint_bilateral_filter(j3, grey, -1, 20.0, 22.0)
             assert np.array_equal(got.cpu().numpy()[0], want), (h, as_bgr)
-            only64 = rf.ops.joint_bilateral_u8(jd, sd, -1, 20.0, 22.0, grey_as_bgr=as_bgr,
-                                               flags=0x4000)
+            with rf._ffi.debug_options(jbf_tile64_only=1):
+                only64 = rf.ops.joint_bilateral_u8(jd, sd, -1, 20.0, 22.0, grey_as_bgr=as_bgr)
             assert torch.equal(only64, got), (h, as_bgr)
         if h > 64:
             continue  # (the 3-channel cases below on the small heights only, for time)
@@ -250,7 +252,8 @@ def test_jbf_strip_tiles(env):
             got = rf.ops.joint_bilateral_u8(jd, sd, -1, 20.0, 22.0)
             assert np.array_equal(got.cpu().numpy()[0],
                                   co.joint_bilateral_filter(joint, src3, -1, 20.0, 22.0)), h
-            assert torch.equal(rf.ops.joint_bilateral_u8(jd, sd, -1, 20.0, 22.0, flags=0x4000), got)
+            with rf._ffi.debug_options(jbf_tile64_only=1):
+                assert torch.equal(rf.ops.joint_bilateral_u8(jd, sd, -1, 20.0, 22.0), got)
 
 
 @pytest.mark.parametrize("h,w", [(500, 333), (130, 96), (200, 20), (129, 65), (333, 500),
@@ -268,8 +271,9 @@ def test_jbf_right_and_bottom_strips(env, h, w):
         j3 = jt if jt.shape[2] == 3 else np.repeat(jt, 3, axis=2)
         assert np.array_equal(got.cpu().numpy()[0],
                               co.joint_bilateral_filter(j3, grey, -1, 20.0, 22.0)), as_bgr
-        assert torch.equal(rf.ops.joint_bilateral_u8(jd, sd, -1, 20.0, 22.0, grey_as_bgr=as_bgr,
-                                                     flags=0x4000), got)
+        with rf._ffi.debug_options(jbf_tile64_only=1):
+            assert torch.equal(rf.ops.joint_bilateral_u8(jd, sd, -1, 20.0, 22.0,
+                                                         grey_as_bgr=as_bgr), got)
 
 
 def test_gf_randomised_sweep(env):
@@ -447,8 +451,9 @@ def test_grey_as_bgr_and_fused_chain(env):
     g1, j1 = _dev(torch, grey[:, :, None], joint[:, :, None])
     want = co.joint_bilateral_filter(np.repeat(joint[:, :, None], 3, 2),
                                      np.repeat(grey[:, :, None], 3, 2), -1, 20, 22)
-    for flags in (0, rf._ffi.JBF_FORCE_GENERIC, 1 << 8):
-        got = rf.ops.joint_bilateral_u8(j1, g1, -1, 20, 22, flags=flags, grey_as_bgr=True)
+    for flags, tune in ((0, 0), (rf._ffi.JBF_FORCE_GENERIC, 0), (0, 1)):
+        with rf._ffi.debug_options(jbf_tune=tune):       # tune 1: the 64xTH kernel
+            got = rf.ops.joint_bilateral_u8(j1, g1, -1, 20, 22, flags=flags, grey_as_bgr=True)
         assert np.array_equal(got[0, :, :, 0].cpu().numpy(), want[:, :, 0]), flags
     # without the flag a 1-channel joint keeps OpenCV's 1-channel semantics (distance |d|)
     plain = rf.ops.joint_bilateral_u8(j1, g1, -1, 20, 22)

@@ -47,6 +47,7 @@ def main():
         lib.rf_jbf_u8.argtypes = _ffi.load_library().rf_jbf_u8.argtypes
         lib.rf_jbf_u8.restype = ctypes.c_int
         lib.rf_last_error.restype = ctypes.c_char_p
+        lib.rf_debug_option.argtypes = [ctypes.c_char_p, ctypes.c_int]
         libs.append((os.path.basename(path), lib))
     variants = [int(v) for v in args.variants.split(",")]
     stream = _ffi.current_stream_ptr(torch)
@@ -57,9 +58,16 @@ def main():
         if tune >= 100:  # variant + 100 = the same variant with --extra-flags set
             tune -= 100
             extra = args.extra_flags
+        # kernel variant and stage-only are debug options (include/reflectance_filtering_debug.h);
+        # --extra-flags: bit 0x2000 / 0x4000 of older builds = jbf_compiler_loop / jbf_tile64_only
+        lib.rf_debug_option(b"jbf_tune", tune)
+        lib.rf_debug_option(b"jbf_stage_only", 1 if args.stage_only else 0)
+        lib.rf_debug_option(b"jbf_compiler_loop", 1 if extra & 0x2000 else 0)
+        lib.rf_debug_option(b"jbf_tile64_only", 1 if extra & 0x4000 else 0)
         rc = lib.rf_jbf_u8(joint.data_ptr(), src.data_ptr(), out.data_ptr(), n, h, w, 3, 3, -1,
-                           args.sigma_color, args.sigma_spatial, 4,
-                           (tune << 8) | extra | (0x1000 if args.stage_only else 0), stream)
+                           args.sigma_color, args.sigma_spatial, 4, extra & 7, stream)
+        lib.rf_debug_option(b"jbf_tune", 0)
+        lib.rf_debug_option(b"jbf_stage_only", 0)
         if rc != 0:
             raise RuntimeError("variant %d: %s" % (tune, lib.rf_last_error()))
 
