@@ -367,7 +367,15 @@ def committed_traffic(n, h, w):
 def run_rank(args):
     stub = os.environ.get("RF_BENCH_STUB") == "1"
     from reflectance_filtering_amd import sharding
-    rank, world, local = sharding.init_distributed(backend="gloo" if stub else None)
+    backend = "gloo" if stub else None
+    if not stub and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        import torch
+        # more ranks than devices (e.g. a 2-rank flow test on a 1-GPU box): RCCL refuses two
+        # ranks on one device, and the job needs no collective on the data path, so the host-side
+        # barrier and the two scalar reductions go over gloo
+        if torch.cuda.device_count() < int(os.environ["WORLD_SIZE"]):
+            backend = "gloo"
+    rank, world, local = sharding.init_distributed(backend=backend)
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with matching values, or "
                          "omit the torchrun environment to let bench.py start the ranks)"
@@ -447,6 +455,10 @@ def run_rank(args):
             rf.ops.release_workspaces()
             torch.cuda.empty_cache()
 
+    if world > 1:
+        import torch.distributed as dist
+        sharding.barrier(world)
+        dist.destroy_process_group()
     if rank != 0:
         return
     value = px_total / 1e6 / t_max

@@ -222,19 +222,31 @@ __global__ __launch_bounds__(kCnnThreads) void cnn_reflectance_kernel(
     }
 }
 
+// One packed copy of the weights per (device, stream): a call re-packs the caller's weights on
+// its own stream (18 tiny workgroups; the weights may have changed since the last call), so calls
+// on different streams of one device never share a buffer and calls on one stream are ordered.
+struct PackedSlot {
+    int device;
+    hipStream_t stream;
+    float *buf;
+};
 std::mutex g_cnn_mu;
-std::vector<float *> g_packed;  // per device
+std::vector<PackedSlot> g_packed;
 
-int packed_buffer(float **out)
+int packed_buffer(hipStream_t stream, float **out)
 {
     int dev = 0;
     RF_HIP_CHECK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(g_cnn_mu);
-    if ((int)g_packed.size() <= dev)
-        g_packed.resize(dev + 1, nullptr);
-    if (!g_packed[dev])
-        RF_HIP_CHECK(hipMalloc(&g_packed[dev], sizeof(float) * kPackedFloats));
-    *out = g_packed[dev];
+    for (const PackedSlot &s : g_packed)
+        if (s.device == dev && s.stream == stream) {
+            *out = s.buf;
+            return RF_OK;
+        }
+    float *buf = nullptr;
+    RF_HIP_CHECK(hipMalloc(&buf, sizeof(float) * kPackedFloats));
+    g_packed.push_back({dev, stream, buf});
+    *out = buf;
     return RF_OK;
 }
 
@@ -243,8 +255,8 @@ int packed_buffer(float **out)
 void cnn_shutdown()
 {
     std::lock_guard<std::mutex> lock(g_cnn_mu);
-    for (float *p : g_packed)
-        (void)hipFree(p);
+    for (const PackedSlot &s : g_packed)
+        (void)hipFree(s.buf);
     g_packed.clear();
 }
 
@@ -266,12 +278,10 @@ extern "C" int rf_cnn_reflectance_u8(const uint8_t *bgr, float *r_out, uint8_t *
         return RF_OK;
     hipStream_t stream = (hipStream_t)stream_;
     float *packed = nullptr;
-    int rc = packed_buffer(&packed);
+    int rc = packed_buffer(stream, &packed);
     if (rc != RF_OK)
         return rc;
-    // (the packed copy is rebuilt on the caller's stream every call: the weights may have changed,
-    //  and calls on one stream are ordered; concurrent calls on different streams of one device
-    //  must use the same weights)
+    // (the packed copy is rebuilt on the caller's stream every call: the weights may have changed)
     hipLaunchKernelGGL(cnn_pack_weights_kernel, dim3((RF_CNN_NPARAMS + 255) / 256), dim3(256), 0,
                        stream, weights, packed);
     const size_t npix = (size_t)n * h * w;

@@ -871,9 +871,9 @@ extern "C" size_t rf_gf_workspace_bytes(int n, int h, int w, int guide_cn, int s
     if (n <= 0 || h <= 0 || w <= 0 || (src_cn != 1 && src_cn != 3))
         return 0;
     const size_t per_img = (size_t)h * w * (4 * src_cn) * (sizeof(float) + sizeof(double));
-    // enough images in flight to fill the chip, capped at 16 GiB of scratch
+    // enough images in flight to fill the chip, capped at 6 GiB of scratch
     size_t imgs = (size_t)n;
-    const size_t cap = (size_t)16 << 30;
+    const size_t cap = (size_t)6 << 30;
     if (imgs * per_img > cap)
         imgs = cap / per_img;
     if (imgs < 1)

@@ -20,6 +20,7 @@
 // pre-scaled texels make v_sad_u32 produce the gather address).
 #include <cfloat>
 #include <cmath>
+#include <memory>
 #include <mutex>
 #include <type_traits>
 #include <vector>
@@ -56,20 +57,31 @@ struct JbfTables {
     // the disk (the weights are symmetric in i and in j)
     int r4 = 0, sw_len = 0;
     float *d_swsym = nullptr;
+    std::shared_ptr<void> keep;  // JbfTableOwner of the arrays above
+};
+
+// Owns the device arrays of one cache entry.  rf_jbf_u8 keeps a reference for the duration of
+// the call, so an eviction (or rf_shutdown) on another thread cannot free tables that a call has
+// looked up but not launched yet; the last reference frees them on their own device (hipFree
+// waits for the work queued there).  A failed allocation midway frees what was allocated.
+struct JbfTableOwner {
+    int device = 0;
+    void *ptrs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    ~JbfTableOwner()
+    {
+        int cur = 0;
+        const bool switched = hipGetDevice(&cur) == hipSuccess && cur != device &&
+                              hipSetDevice(device) == hipSuccess;
+        for (void *p : ptrs)
+            if (p)
+                (void)hipFree(p);
+        if (switched)
+            (void)hipSetDevice(cur);
+    }
 };
 
 std::mutex g_mu;
 std::vector<JbfTables> g_tables;
-
-void free_tables(JbfTables &t)
-{
-    (void)hipFree(t.d_lut);
-    (void)hipFree(t.d_di);
-    (void)hipFree(t.d_dj);
-    (void)hipFree(t.d_sw);
-    (void)hipFree(t.d_hw);
-    (void)hipFree(t.d_swsym);
-}
 
 // Host-side parameter tables, computed in double exactly like jointBilateralFilter_8u does.
 int get_tables(int radius, int joint_cn, double sigma_color, double sigma_space, JbfTables *out)
@@ -124,25 +136,38 @@ int get_tables(int radius, int joint_cn, double sigma_color, double sigma_space,
     for (size_t k = 0; k < di.size(); k++)
         if (di[k] >= 0)
             swsym[(size_t)di[k] * t.sw_len + (t.r4 + 8) + dj[k]] = sw[k];
+    auto owner = std::make_shared<JbfTableOwner>();
+    owner->device = dev;
+    t.keep = owner;
     RF_HIP_CHECK(hipMalloc(&t.d_swsym, sizeof(float) * swsym.size()));
+    owner->ptrs[0] = t.d_swsym;
     RF_HIP_CHECK(hipMemcpy(t.d_swsym, swsym.data(), sizeof(float) * swsym.size(),
                            hipMemcpyHostToDevice));
     RF_HIP_CHECK(hipMalloc(&t.d_lut, sizeof(float) * nlut));
+    owner->ptrs[1] = t.d_lut;
     RF_HIP_CHECK(hipMalloc(&t.d_di, sizeof(int) * t.maxk));
+    owner->ptrs[2] = t.d_di;
     RF_HIP_CHECK(hipMalloc(&t.d_dj, sizeof(int) * t.maxk));
+    owner->ptrs[3] = t.d_dj;
     RF_HIP_CHECK(hipMalloc(&t.d_sw, sizeof(float) * t.maxk));
+    owner->ptrs[4] = t.d_sw;
     RF_HIP_CHECK(hipMalloc(&t.d_hw, sizeof(int) * d));
+    owner->ptrs[5] = t.d_hw;
     RF_HIP_CHECK(hipMemcpy(t.d_lut, lut.data(), sizeof(float) * nlut, hipMemcpyHostToDevice));
     RF_HIP_CHECK(hipMemcpy(t.d_di, di.data(), sizeof(int) * t.maxk, hipMemcpyHostToDevice));
     RF_HIP_CHECK(hipMemcpy(t.d_dj, dj.data(), sizeof(int) * t.maxk, hipMemcpyHostToDevice));
     RF_HIP_CHECK(hipMemcpy(t.d_sw, sw.data(), sizeof(float) * t.maxk, hipMemcpyHostToDevice));
     RF_HIP_CHECK(hipMemcpy(t.d_hw, hw.data(), sizeof(int) * d, hipMemcpyHostToDevice));
-    // bounded cache: parameter sweeps must not accumulate device memory; evicting is safe only
-    // when no launch that uses the evicted tables is still queued, so sync this device first
+    // bounded cache (parameter sweeps must not accumulate device memory): drop the oldest entry,
+    // of this device if there is one; its arrays are freed when the last call using them returns
     if (g_tables.size() >= 64) {
-        RF_HIP_CHECK(hipDeviceSynchronize());
-        free_tables(g_tables.front());
-        g_tables.erase(g_tables.begin());
+        size_t victim = 0;
+        for (size_t i = 0; i < g_tables.size(); i++)
+            if (g_tables[i].device == dev) {
+                victim = i;
+                break;
+            }
+        g_tables.erase(g_tables.begin() + victim);
     }
     g_tables.push_back(t);
     *out = t;
@@ -1417,9 +1442,7 @@ __global__ __launch_bounds__(256) void jbf_f32_kernel(
 void jbf_shutdown()
 {
     std::lock_guard<std::mutex> lock(g_mu);
-    for (JbfTables &t : g_tables)
-        free_tables(t);
-    g_tables.clear();
+    g_tables.clear();  // arrays are freed by their owners (calls in flight keep theirs alive)
 }
 
 }  // namespace rf

@@ -23,8 +23,9 @@ import numpy as np
 
 try:  # Pillow is optional; the PNG fallback below covers the formats the tools produce
     from PIL import Image as _PILImage
+    from PIL import ImageOps as _PILImageOps
 except Exception:  # pragma: no cover - depends on the environment
-    _PILImage = None
+    _PILImage = _PILImageOps = None
 
 _SRGB_KNEE = 0.04045
 _LINEAR_KNEE = 0.0031308
@@ -227,9 +228,12 @@ def _read_any(filename):
         if _PILImage is not None:
             with _PILImage.open(filename) as im:
                 if im.mode in ("I;16", "I;16B", "I;16L", "I"):
-                    arr = np.asarray(im)
-                    arr = (arr >> 8).astype(np.uint8) if arr.max() > 255 else arr.astype(np.uint8)
+                    # cv2.imread(IMREAD_COLOR) always reduces 16-bit samples to their high byte:
+                    # decided by the file's bit depth (Pillow's mode), never by the value range
+                    arr = (np.asarray(im).astype(np.uint32) >> 8).astype(np.uint8)
                     return np.ascontiguousarray(np.repeat(arr[:, :, None], 3, axis=2))
+                if _PILImageOps is not None and getattr(im, "format", None) in ("JPEG", "MPO", "TIFF"):
+                    im = _PILImageOps.exif_transpose(im)   # cv2.imread applies the EXIF orientation
                 rgb = np.asarray(im.convert("RGB"), dtype=np.uint8)
             return np.ascontiguousarray(rgb[:, :, ::-1])
         with open(filename, "rb") as fh:

@@ -48,9 +48,14 @@ def joint_bilateral_u8(joint, src, d, sigma_color, sigma_space, border=_ffi.BORD
 
 
 def gf_workspace(n, h, w, scn, radius, device, torch):
+    """Guided-filter scratch for the CURRENT stream of `device`, cached per (device, stream):
+    two streams (or threads with their own streams) never share planes.  The cache keeps one
+    buffer per key, sized by rf_gf_workspace_bytes (capped at 6 GiB); release_workspaces()
+    drops them."""
     lib = _ffi.load_library()
     need = lib.rf_gf_workspace_bytes(n, h, w, 3, scn, radius)
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+    dev = device.index if device.index is not None else torch.cuda.current_device()
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
     ws = _gf_workspaces.get(key)
     if ws is None or ws.numel() < need:
         _gf_workspaces.pop(key, None)

@@ -70,24 +70,41 @@ def jointBilateralFilter(joint, src, d, sigmaColor, sigmaSpace, dst=None,
     return res
 
 
+CV_8U, CV_32F = 0, 5
+
+
 def guidedFilter(guide, src, radius, eps, dst=None, dDepth=-1):
     """cv2.ximgproc.guidedFilter(guide, src, radius, eps[, dst[, dDepth]]) for a 3-channel
-    guide and a 1- or 3-channel src, both uint8 or both float32 (dDepth must stay -1: the
-    result has the depth of src)."""
-    if dDepth != -1:
-        raise ValueError("guidedFilter: only dDepth=-1 (result of src's depth) is supported")
+    guide and a 1- or 3-channel src, each uint8 or float32.  dDepth = -1 (depth of src), CV_8U
+    or CV_32F.  uint8 guide + uint8 src + uint8 result is the reference's call
+    (/root/reference/filter_reflectance.py:67-70) and runs the 8-bit kernels; every other
+    combination runs the float kernels on the values as they are (OpenCV converts without
+    scaling) and, for an 8-bit result, rounds like saturate_cast<uchar> - on 8-bit inputs the
+    same bytes as the 8-bit kernels, whose float core it is."""
     torch = _ffi.require_gpu()
-    if np.asarray(guide).shape[:2] != np.asarray(src).shape[:2]:
+    g_np, s_np = np.asarray(guide), np.asarray(src)
+    if g_np.shape[:2] != s_np.shape[:2]:
         raise ValueError("guide and src must have the same size")
-    if np.asarray(guide).dtype != np.asarray(src).dtype:
-        raise ValueError("guide and src must have the same depth")
-    g = _to_device(guide, "guide", torch)
-    s = _to_device(src, "src", torch)
-    if s.dtype == torch.float32:
-        out = ops.guided_filter_f32(g, s, radius, eps)
+    if dDepth == -1:
+        want = s_np.dtype
+    elif dDepth in (CV_8U, CV_32F):
+        want = np.dtype(np.uint8 if dDepth == CV_8U else np.float32)
     else:
-        out = ops.guided_filter_u8(g, s, radius, eps)
-    res = _to_host(out, src)
+        raise ValueError("guidedFilter: dDepth must be -1, CV_8U (0) or CV_32F (5)")
+    if g_np.dtype == np.uint8 and s_np.dtype == np.uint8 and want == np.uint8:
+        out = ops.guided_filter_u8(_to_device(guide, "guide", torch), _to_device(src, "src", torch),
+                                   radius, eps)
+        res = _to_host(out, src)
+    else:
+        for name, a in (("guide", g_np), ("src", s_np)):
+            if a.dtype not in (np.uint8, np.float32):
+                raise ValueError("%s: only 8-bit and float32 images are supported (got %s)"
+                                 % (name, a.dtype))
+        out = ops.guided_filter_f32(_to_device(g_np.astype(np.float32), "guide", torch),
+                                    _to_device(s_np.astype(np.float32), "src", torch), radius, eps)
+        res = _to_host(out, src)
+        if want == np.uint8:   # saturate_cast<uchar>: round half to even, clamp, NaN -> 0
+            res = np.clip(np.rint(np.nan_to_num(res, nan=0.0)), 0, 255).astype(np.uint8)
     if dst is not None:
         np.copyto(dst, res)
         return dst

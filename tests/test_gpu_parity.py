@@ -19,7 +19,8 @@ def env(built):
     import torch
     import reflectance_filtering_amd as rf
     from oracle import c_oracle as co
-    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device visible (run with -m 'not gpu' on CPU-only machines)")
     rf._ffi.load_library()
     return rf, co, torch
 

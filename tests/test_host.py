@@ -247,3 +247,30 @@ def test_no_oracle_in_product():
                 with open(os.path.join(root, f)) as fh:
                     text = fh.read()
                 assert "oracle" not in text.replace("no oracle", ""), os.path.join(root, f)
+
+
+def test_imread_16bit_png_keeps_the_high_byte_whatever_the_values(tmp_path):
+    """cv2.imread(IMREAD_COLOR) reduces 16-bit samples to 8 bits by bit depth: a DARK 16-bit
+    image (all values <= 255) must decode to zeros, not to its low bytes."""
+    import struct
+    import zlib
+    from reflectance_filtering_amd import image_utils as iu
+
+    def png16(values):
+        h, w = values.shape
+        raw = b"".join(b"\x00" + values[r].astype(">u2").tobytes() for r in range(h))
+
+        def chunk(tag, body):
+            return (struct.pack(">I", len(body)) + tag + body
+                    + struct.pack(">I", zlib.crc32(tag + body) & 0xFFFFFFFF))
+        return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 16, 0, 0, 0, 0))
+                + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+
+    dark = np.arange(12, dtype=np.uint16).reshape(3, 4) * 20          # max 220 < 256
+    bright = dark * 256 + 7
+    for vals in (dark, bright):
+        f = tmp_path / "x.png"
+        f.write_bytes(png16(vals))
+        got = iu.imread(str(f))
+        assert got.shape == (3, 4, 3) and got.dtype == np.uint8
+        assert np.array_equal(got[:, :, 0], (vals >> 8).astype(np.uint8))
