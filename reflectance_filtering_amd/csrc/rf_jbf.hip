@@ -819,6 +819,202 @@ __device__ __forceinline__ void jbf_tap_loop_grey4(uint32_t lut_lane_addr, uint3
 #undef RF_G4_PART2
 #undef RF_TEXEL_OFF4
 }
+
+// Hand-scheduled tap loop for colour tiles with 6-byte texels (main plane {B,G,R joint, B src},
+// second plane {G src, R src}): the arithmetic and the pipeline of jbf_tap_loop<3, LUTREP, false,
+// TLW, 6>, the row-carried prologue of jbf_tap_loop_grey4.  Per column step 44 VALU instructions,
+// 12 of them on the full pipe (v_and with the literal mask kept in a VGPR is not): 4 v_sad_u8,
+// 4 v_lshl_add_u32, 3 v_cvt_f32_ubyte*; hipcc emits the SADs and address computations as one
+// burst of nine, here each full-pipe instruction is followed by a simple one (v_mul/v_add).
+template <int LUTREP, int TLW>
+__device__ __forceinline__ void jbf_tap_loop_rgb6(uint32_t lut_lane_addr, uint32_t sw_addr0,
+                                                  uint32_t tile_lane_addr,
+                                                  uint32_t plane_b_lane_addr,
+                                                  const uint32_t (&jc)[kPix], int ty, int radius,
+                                                  int r4, int sw_len,
+                                                  const int *__restrict__ hwtab,
+                                                  float (&sum)[kPix][3], float (&wsum)[kPix])
+{
+    constexpr int Q4 = TLW / 4;
+    constexpr int SHIFT = LUTREP == 32 ? 7 : LUTREP == 16 ? 6 : LUTREP == 8 ? 5 : 4;
+    static_assert(LUTREP == 32 || LUTREP == 16 || LUTREP == 8 || LUTREP == 4, "LUT replicas");
+    uint32_t mask = 0x00ffffffu;
+    asm volatile("" : "+v"(mask));  // keep the mask in a VGPR (a literal operand is full-pipe)
+
+    auto row_addr = [&](int i, uint32_t &ta_out, uint32_t &tb_out, uint32_t &wa_out,
+                        int &ngroups_out) {
+        const int hw = hwtab[i + radius];
+        const int hw4 = (hw + 3) & ~3;
+        const int ai = i < 0 ? -i : i;
+        const uint32_t texel0 = (uint32_t)((ty + i + radius) * TLW + ((r4 - hw4) >> 2));
+        ta_out = tile_lane_addr + texel0 * 4;
+        tb_out = plane_b_lane_addr + texel0 * 2;
+        wa_out = sw_addr0 + (uint32_t)((ai * sw_len + (r4 + 8) + hw4 - 4) * 4);
+        ngroups_out = (hw4 >> 1) + 1;
+    };
+
+    uint32_t tq[4], tqb[4];
+    float4v wna, wnb;
+    float gg[2][kPix];
+    uint32_t ta, tb, wa_addr;
+    int ngroups;
+    row_addr(-radius, ta, tb, wa_addr, ngroups);
+    // prologue of the first tap row (later rows get theirs from the last group of the row before)
+    asm volatile("ds_read_b32 %0, %4\n\t"
+                 "ds_read_b32 %1, %4 offset:%6\n\t"
+                 "ds_read_u16 %2, %5\n\t"
+                 "ds_read_u16 %3, %5 offset:%7"
+                 : "=&v"(tq[0]), "=&v"(tq[1]), "=&v"(tqb[0]), "=&v"(tqb[1])
+                 : "v"(ta), "v"(tb), "n"(Q4 * 4), "n"(Q4 * 2));
+    asm volatile("ds_read_b128 %0, %2\n\t"
+                 "ds_read_b128 %1, %2 offset:16"
+                 : "=&v"(wna), "=&v"(wnb)
+                 : "v"(wa_addr));
+    asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(tq[0]));
+    {
+        const uint32_t tj = tq[0] & mask;
+#pragma unroll
+        for (int p = 0; p < kPix; p++) {
+            const uint32_t a = __builtin_amdgcn_sad_u8(tj, jc[p], 0u) * (LUTREP * 4u) + lut_lane_addr;
+            asm volatile("ds_read_b32 %0, %1" : "=v"(gg[0][p]) : "v"(a));
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(tq[1]), "+v"(tqb[0]), "+v"(tqb[1]), "+v"(wna), "+v"(wnb), "+v"(gg[0][0]),
+                   "+v"(gg[0][1]), "+v"(gg[0][2]), "+v"(gg[0][3]));
+
+#define RF_TEXEL_OFFC(U) ((((U) + 2) & 3) * Q4 + (((U) + 2) >> 2))
+    // Column step U: texel (both planes) of column +2 from TA/TB + offset, SAD + gathers of column
+    // +1, accumulation of column +0.  GA = gathers consumed, GB = gathers issued (their registers
+    // hold alpha, then the LDS address, then the LUT value).
+#define RF_C6_STEP(U, GA, GB, TA, TB, OFFT, EXTRA_ASM, EXTRA_OPERANDS)                           \
+    {                                                                                            \
+        float w0_, w1_, w2_, w3_, s0_, s1_, s2_, m0_, m1_, m2_, m3_;                             \
+        uint32_t tj_;                                                                            \
+        asm volatile("ds_read_b32 %[tn], %[ta] offset:%[off4]\n\t"                               \
+                     "ds_read_u16 %[tnb], %[tb] offset:%[off2]\n\t"                              \
+                     "v_and_b32 %[tj], %[mask], %[t1]\n\t"                                       \
+                     "v_sad_u8 %[a0], %[tj], %[jc0], 0\n\t"                                      \
+                     "v_mul_f32 %[w0], %[wv0], %[g0]\n\t"                                        \
+                     "v_sad_u8 %[a1], %[tj], %[jc1], 0\n\t"                                      \
+                     "v_mul_f32 %[w1], %[wv1], %[g1]\n\t"                                        \
+                     "v_sad_u8 %[a2], %[tj], %[jc2], 0\n\t"                                      \
+                     "v_mul_f32 %[w2], %[wv2], %[g2]\n\t"                                        \
+                     "v_sad_u8 %[a3], %[tj], %[jc3], 0\n\t"                                      \
+                     "v_mul_f32 %[w3], %[wv3], %[g3]\n\t"                                        \
+                     "v_cvt_f32_ubyte3 %[s0], %[t0]\n\t"                                         \
+                     "v_add_f32 %[ws0], %[ws0], %[w0]\n\t"                                       \
+                     "v_cvt_f32_ubyte0 %[s1], %[tb0]\n\t"                                        \
+                     "v_add_f32 %[ws1], %[ws1], %[w1]\n\t"                                       \
+                     "v_cvt_f32_ubyte1 %[s2], %[tb0]\n\t"                                        \
+                     "v_add_f32 %[ws2], %[ws2], %[w2]"                                           \
+                     : [tn] "=&v"(tq[((U) + 2) & 3]), [tnb] "=&v"(tqb[((U) + 2) & 3]),           \
+                       [tj] "=&v"(tj_), [a0] "=&v"(GB[0]), [a1] "=&v"(GB[1]), [a2] "=&v"(GB[2]), \
+                       [a3] "=&v"(GB[3]), [w0] "=&v"(w0_), [w1] "=&v"(w1_), [w2] "=&v"(w2_),     \
+                       [w3] "=&v"(w3_), [s0] "=&v"(s0_), [s1] "=&v"(s1_), [s2] "=&v"(s2_),       \
+                       [ws0] "+v"(wsum[0]), [ws1] "+v"(wsum[1]), [ws2] "+v"(wsum[2])             \
+                     : [ta] "v"(TA), [tb] "v"(TB), [off4] "n"((OFFT) * 4), [off2] "n"((OFFT) * 2), \
+                       [mask] "v"(mask), [t1] "v"(tq[((U) + 1) & 3]), [t0] "v"(tq[(U)]),         \
+                       [tb0] "v"(tqb[(U)]), [jc0] "v"(jc[0]), [jc1] "v"(jc[1]), [jc2] "v"(jc[2]), \
+                       [jc3] "v"(jc[3]), [wv0] "v"(wv[4 - (U)]), [wv1] "v"(wv[5 - (U)]),         \
+                       [wv2] "v"(wv[6 - (U)]), [wv3] "v"(wv[7 - (U)]), [g0] "v"(GA[0]),          \
+                       [g1] "v"(GA[1]), [g2] "v"(GA[2]), [g3] "v"(GA[3]));                       \
+        asm volatile("v_lshl_add_u32 %[a0], %[a0], %[sh], %[la]\n\t"                             \
+                     "v_add_f32 %[ws3], %[ws3], %[w3]\n\t"                                       \
+                     "v_lshl_add_u32 %[a1], %[a1], %[sh], %[la]\n\t"                             \
+                     "v_mul_f32 %[m0], %[w0], %[s0]\n\t"                                         \
+                     "v_lshl_add_u32 %[a2], %[a2], %[sh], %[la]\n\t"                             \
+                     "v_mul_f32 %[m1], %[w1], %[s0]\n\t"                                         \
+                     "v_lshl_add_u32 %[a3], %[a3], %[sh], %[la]\n\t"                             \
+                     "v_mul_f32 %[m2], %[w2], %[s0]\n\t"                                         \
+                     "ds_read_b32 %[a0], %[a0]\n\t"                                              \
+                     "ds_read_b32 %[a1], %[a1]\n\t"                                              \
+                     "ds_read_b32 %[a2], %[a2]\n\t"                                              \
+                     "ds_read_b32 %[a3], %[a3]"                                                  \
+                     : [a0] "+v"(GB[0]), [a1] "+v"(GB[1]), [a2] "+v"(GB[2]), [a3] "+v"(GB[3]),   \
+                       [ws3] "+v"(wsum[3]), [m0] "=&v"(m0_), [m1] "=&v"(m1_), [m2] "=&v"(m2_)    \
+                     : [sh] "n"(SHIFT), [la] "v"(lut_lane_addr), [w0] "v"(w0_), [w1] "v"(w1_),   \
+                       [w2] "v"(w2_), [w3] "v"(w3_), [s0] "v"(s0_));                             \
+        EXTRA_ASM                                                                                \
+        asm volatile("v_mul_f32 %[m3], %[w3], %[s0]\n\t"                                         \
+                     "v_add_f32 %[c00], %[c00], %[m0]\n\t"                                       \
+                     "v_add_f32 %[c10], %[c10], %[m1]\n\t"                                       \
+                     "v_add_f32 %[c20], %[c20], %[m2]\n\t"                                       \
+                     "v_add_f32 %[c30], %[c30], %[m3]\n\t"                                       \
+                     "v_mul_f32 %[m0], %[w0], %[s1]\n\t"                                         \
+                     "v_mul_f32 %[m1], %[w1], %[s1]\n\t"                                         \
+                     "v_mul_f32 %[m2], %[w2], %[s1]\n\t"                                         \
+                     "v_mul_f32 %[m3], %[w3], %[s1]\n\t"                                         \
+                     "v_add_f32 %[c01], %[c01], %[m0]\n\t"                                       \
+                     "v_add_f32 %[c11], %[c11], %[m1]\n\t"                                       \
+                     "v_add_f32 %[c21], %[c21], %[m2]\n\t"                                       \
+                     "v_add_f32 %[c31], %[c31], %[m3]\n\t"                                       \
+                     "v_mul_f32 %[m0], %[w0], %[s2]\n\t"                                         \
+                     "v_mul_f32 %[m1], %[w1], %[s2]\n\t"                                         \
+                     "v_mul_f32 %[m2], %[w2], %[s2]\n\t"                                         \
+                     "v_mul_f32 %[m3], %[w3], %[s2]\n\t"                                         \
+                     "v_add_f32 %[c02], %[c02], %[m0]\n\t"                                       \
+                     "v_add_f32 %[c12], %[c12], %[m1]\n\t"                                       \
+                     "v_add_f32 %[c22], %[c22], %[m2]\n\t"                                       \
+                     "v_add_f32 %[c32], %[c32], %[m3]\n\t"                                       \
+                     "s_waitcnt lgkmcnt(0)"                                                      \
+                     : [m0] "+v"(m0_), [m1] "+v"(m1_), [m2] "+v"(m2_), [m3] "=&v"(m3_),          \
+                       [c00] "+v"(sum[0][0]), [c10] "+v"(sum[1][0]), [c20] "+v"(sum[2][0]),      \
+                       [c30] "+v"(sum[3][0]), [c01] "+v"(sum[0][1]), [c11] "+v"(sum[1][1]),      \
+                       [c21] "+v"(sum[2][1]), [c31] "+v"(sum[3][1]), [c02] "+v"(sum[0][2]),      \
+                       [c12] "+v"(sum[1][2]), [c22] "+v"(sum[2][2]), [c32] "+v"(sum[3][2]),      \
+                       "+v"(tq[((U) + 2) & 3]), "+v"(tqb[((U) + 2) & 3]), "+v"(GB[0]),           \
+                       "+v"(GB[1]), "+v"(GB[2]), "+v"(GB[3]) EXTRA_OPERANDS                      \
+                     : [w0] "v"(w0_), [w1] "v"(w1_), [w2] "v"(w2_), [w3] "v"(w3_),               \
+                       [s0] "v"(s0_), [s1] "v"(s1_), [s2] "v"(s2_));                             \
+    }
+#define RF_C6_NOASM
+#define RF_C6_COMMA_W , "+v"(wna), "+v"(wnb)
+#define RF_C6_LOAD_WINDOW(ADDR)                                                                  \
+    asm volatile("ds_read_b128 %0, %2\n\t"                                                       \
+                 "ds_read_b128 %1, %2 offset:16"                                                 \
+                 : "=&v"(wna), "=&v"(wnb)                                                        \
+                 : "v"(ADDR));
+
+    for (int i = -radius; i <= radius; i++) {
+        uint32_t ta_next, tb_next, wa_next;
+        int ngroups_next;
+        row_addr(i < radius ? i + 1 : i, ta_next, tb_next, wa_next, ngroups_next);
+        for (int gq = 0; gq < ngroups - 1; gq++) {
+            float wv[8];
+            wv[0] = wna.x; wv[1] = wna.y; wv[2] = wna.z; wv[3] = wna.w;
+            wv[4] = wnb.x; wv[5] = wnb.y; wv[6] = wnb.z; wv[7] = wnb.w;
+            RF_C6_STEP(0, gg[0], gg[1], ta, tb, RF_TEXEL_OFFC(0), RF_C6_NOASM, )
+            RF_C6_STEP(1, gg[1], gg[0], ta, tb, RF_TEXEL_OFFC(1), RF_C6_NOASM, )
+            RF_C6_STEP(2, gg[0], gg[1], ta, tb, RF_TEXEL_OFFC(2), RF_C6_NOASM, )
+            wa_addr -= 16;
+            RF_C6_STEP(3, gg[1], gg[0], ta, tb, RF_TEXEL_OFFC(3), RF_C6_LOAD_WINDOW(wa_addr),
+                       RF_C6_COMMA_W)
+            ta += 4;
+            tb += 2;
+        }
+        {
+            float wv[8];
+            wv[0] = wna.x; wv[1] = wna.y; wv[2] = wna.z; wv[3] = wna.w;
+            wv[4] = wnb.x; wv[5] = wnb.y; wv[6] = wnb.z; wv[7] = wnb.w;
+            RF_C6_STEP(0, gg[0], gg[1], ta, tb, RF_TEXEL_OFFC(0), RF_C6_NOASM, )
+            RF_C6_STEP(1, gg[1], gg[0], ta, tb, RF_TEXEL_OFFC(1), RF_C6_NOASM, )
+            // the columns past the end of this row carry no weight: fetch the next row's first two
+            RF_C6_STEP(2, gg[0], gg[1], ta_next, tb_next, 0, RF_C6_NOASM, )
+            RF_C6_STEP(3, gg[1], gg[0], ta_next, tb_next, Q4, RF_C6_LOAD_WINDOW(wa_next),
+                       RF_C6_COMMA_W)
+        }
+        ta = ta_next;
+        tb = tb_next;
+        wa_addr = wa_next;
+        ngroups = ngroups_next;
+    }
+#undef RF_C6_LOAD_WINDOW
+#undef RF_C6_COMMA_W
+#undef RF_C6_NOASM
+#undef RF_C6_STEP
+#undef RF_TEXEL_OFFC
+}
 #undef RF_LDS_READ_B64
 #undef RF_LDS_READ_B128
 #undef RF_LDS_READ_B32
@@ -1092,10 +1288,16 @@ __global__ __launch_bounds__(1024) void jbf_tile64_kernel(
                 sum[p][0] = sum[p][1] = sum[p][2] = 0.f;
             }
             const uint32_t lut_lane_addr = lds_addr(lut_c) + (uint32_t)(tid & (CREP - 1)) * 4u;
-            jbf_tap_loop<3, CREP, false, TLW, 6>(lut_lane_addr, sw_addr0,
-                                                 lds_addr(tile4) + (uint32_t)tx * 4u,
-                                                 lds_addr(plane_b) + (uint32_t)tx * 2u, jc, 0u, ty,
-                                                 radius, r4, sw_len, hwtab, sum, wsum);
+            if (flags & kJbfCompilerLoop)  // test aid: compiler-scheduled loop instead of the asm one
+                jbf_tap_loop<3, CREP, false, TLW, 6>(lut_lane_addr, sw_addr0,
+                                                     lds_addr(tile4) + (uint32_t)tx * 4u,
+                                                     lds_addr(plane_b) + (uint32_t)tx * 2u, jc, 0u,
+                                                     ty, radius, r4, sw_len, hwtab, sum, wsum);
+            else
+                jbf_tap_loop_rgb6<CREP, TLW>(lut_lane_addr, sw_addr0,
+                                             lds_addr(tile4) + (uint32_t)tx * 4u,
+                                             lds_addr(plane_b) + (uint32_t)tx * 2u, jc, ty, radius,
+                                             r4, sw_len, hwtab, sum, wsum);
             store_quad<3, 3>(dst, img, tile_y0 + ty, tile_x0 + 4 * tx, h, w, sum, wsum, flags);
             return;
         }

@@ -200,6 +200,13 @@ def test_jbf_row_pipeline(env, sc, ss):
     for opt in ("jbf_compiler_loop", "jbf_tile64_only"):
         with rf._ffi.debug_options(**{opt: 1}):
             assert torch.equal(rf.ops.joint_bilateral_u8(jd, sd, -1, sc, ss), got), opt
+    # colour src: the hand-scheduled 6-byte-texel loop against the oracle and the compiler's loop
+    colour = synth.scene_u8(h, w, seed=int(ss * 10) + 1)
+    (cd,) = _dev(torch, colour)
+    got3 = rf.ops.joint_bilateral_u8(jd, cd, -1, sc, ss)
+    assert np.array_equal(got3.cpu().numpy()[0], co.joint_bilateral_filter(joint, colour, -1, sc, ss))
+    with rf._ffi.debug_options(jbf_compiler_loop=1):
+        assert torch.equal(rf.ops.joint_bilateral_u8(jd, cd, -1, sc, ss), got3)
 
 
 def test_jbf_grey_joint_detected_at_run_time(env):
