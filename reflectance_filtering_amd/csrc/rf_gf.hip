@@ -458,97 +458,103 @@ __global__ __launch_bounds__(64 * 4 * SCN) void gf_colsum_apply_kernel(
 // L2) bytes per pixel and src channel triple.
 // ------------------------------------------------------------------------------------------
 constexpr int kSB = 16;      // columns per state block and per column-walk wave
-constexpr int kRing = 128;   // padded-row ring of gf_rowstate_kernel; needs 2r + 1 <= 112
 
 // planes: [img][src_np][h][w]; states: [img * np + plane][nb][h], nb = ceil(w / 16);
 // states[..][b][row] = RowSum at column 16 b.  grid: (planes of the chunk) x (64-row blocks).
+// One wave per workgroup, lane = row, walking the border-extended row ext[i] = S[bi(i - r)] from
+// its left end.  The value leaving the window, ext[i - ks], is the value that entered ks steps
+// earlier in the same lane: it is kept in a register FIFO of F >= ks floats, F a multiple of 16
+// (slot = step mod F, static because the loop body is one period of F steps, fully unrolled) -
+// no second read and only 4 KB of LDS (the transposition of one chunk of 16 columns), so a dozen
+// waves share a CU and hide each other's memory latency.  The stream is prefixed with PAD dummy
+// steps so that every chunk of 16 steps is a 64-byte-aligned run of 16 source columns.
+template <int R>
 __global__ __launch_bounds__(64) void gf_rowstate_kernel(const float *__restrict__ planes,
                                                          double *__restrict__ states, int h, int w,
-                                                         int radius, int row_blocks, int np,
+                                                         int row_blocks, int np,
                                                          const int *__restrict__ colour, int src_np,
                                                          int nb)
 {
+    constexpr int KS = 2 * R + 1;
+    constexpr int F = (KS + 15) & ~15;
+    constexpr int NCH = F / 16;
+    constexpr int PAD = (16 - R % 16) % 16;  // step t <-> extended index i = t - PAD, column i - R
+    static_assert(KS + PAD <= 2 * F, "the window fills within the two peeled periods");
     const int plane = blockIdx.x / row_blocks;
     if (colour != nullptr && plane % np >= 4 && colour[plane / np] == 0)
         return;  // grey 3-channel images only carry the 4 planes of their first channel
-    __shared__ float ring[kBRows][kRing + 1];
+    __shared__ float tE[kBRows][17];
 
     const int lane = threadIdx.x;
     const int row0 = (blockIdx.x - plane * row_blocks) * kBRows;
     const float *S = planes + ((size_t)(plane / np) * src_np + plane % np) * h * w;
-    double *ST = states + (size_t)plane * nb * h;
-    const int ks = 2 * radius + 1;
-    const int total = w + 2 * radius;  // length of the border-extended row
+    double *ST = states + (size_t)plane * nb * h + row0 + lane;
+    const int total = w + 2 * R + PAD;  // steps
     const int rr = lane >> 4, cc = lane & 15;
     const bool row_ok = row0 + lane < h;
+    uint32_t srow[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        srow[k] = (uint32_t)min(row0 + 4 * k + rr, h - 1) * (uint32_t)w;
 
-    // One wave per workgroup and (33 KB of LDS) one wave per SIMD: nothing but the wave's own
-    // loads in flight hides the HBM latency, so operands are fetched kDepth chunks ahead into
-    // registers (statically rotated: the chunk loop is unrolled by kDepth).
-    constexpr int kDepth = 4;
-    float pre[kDepth][16];
-#define RF_RS_FETCH(slot_, i0_)                                                              \
+    float pre[16];
+#define RF_RS_FETCH(t0_)                                                                     \
     do {                                                                                     \
-        const int sx_ = border_interpolate(min((i0_) + cc, total - 1) - radius, w,           \
+        const int sx_ = border_interpolate(min((t0_) + cc, total - 1) - PAD - R, w,          \
                                            RF_BORDER_REFLECT);                               \
-        _Pragma("unroll") for (int k = 0; k < 16; k++)                                       \
-        {                                                                                    \
-            const int row_ = min(row0 + 4 * k + rr, h - 1);                                  \
-            pre[slot_][k] = S[(size_t)row_ * w + sx_];                                       \
-        }                                                                                    \
+        _Pragma("unroll") for (int k = 0; k < 16; k++) pre[k] = S[srow[k] + sx_];            \
     } while (0)
-    const int cstore = (ks - 1) & 15;  // chunk position after which s is a state (o % 16 == 0)
     double s = 0.0;
-    // one chunk: registers -> ring, refill the slot with the chunk kDepth ahead, run the chain
-#define RF_RS_CHUNK(slot_, i0_)                                                              \
+    float fifo[F];
+    // one chunk of 16 steps; PER = period (0, 1: peeled, window still filling; 2: steady state),
+    // KCH = chunk of the period: step t = t0 + c with (t mod F) = KCH*16 + c static
+#define RF_RS_CHUNK(PER, KCH, t0_)                                                           \
     do {                                                                                     \
-        const int i0c_ = (i0_);                                                              \
-        if (i0c_ < total) {                                                                  \
-            _Pragma("unroll") for (int k = 0; k < 16; k++)                                   \
-                ring[4 * k + rr][(i0c_ + cc) & (kRing - 1)] = pre[slot_][k];                 \
+        const int t0c_ = (t0_);                                                              \
+        if (t0c_ < total) {                                                                  \
             __syncthreads();                                                                 \
-            if (i0c_ + 16 * kDepth < total)                                                  \
-                RF_RS_FETCH(slot_, i0c_ + 16 * kDepth);                                      \
-            if (i0c_ + 16 <= ks - 1) { /* s = ext[0] + ... sequentially from the left end */ \
-                _Pragma("unroll") for (int c = 0; c < 16; c++)                               \
-                    s += (double)ring[lane][(i0c_ + c) & (kRing - 1)];                       \
-            } else if (i0c_ >= ks && i0c_ + 16 <= total) {                                   \
-                _Pragma("unroll") for (int c = 0; c < 16; c++)                               \
-                {                                                                            \
-                    const float e_ = ring[lane][(i0c_ + c) & (kRing - 1)];                   \
-                    const float l_ = ring[lane][(i0c_ + c - ks) & (kRing - 1)];              \
-                    s += (double)e_ - (double)l_;                                            \
-                    if (c == cstore && row_ok)                                               \
-                        ST[(size_t)((i0c_ + c - ks + 1) >> 4) * h + row0 + lane] = s;        \
-                }                                                                            \
-            } else {                                                                         \
-                const int cnt_ = min(16, total - i0c_);                                      \
-                for (int c = 0; c < cnt_; c++) {                                             \
-                    const int i = i0c_ + c;                                                  \
-                    const float e_ = ring[lane][i & (kRing - 1)];                            \
-                    if (i < ks) {                                                            \
+            _Pragma("unroll") for (int k = 0; k < 16; k++) tE[4 * k + rr][cc] = pre[k];      \
+            __syncthreads();                                                                 \
+            if (t0c_ + 16 < total)                                                           \
+                RF_RS_FETCH(t0c_ + 16);                                                      \
+            _Pragma("unroll") for (int c = 0; c < 16; c++)                                   \
+            {                                                                                \
+                const int tp_ = (KCH) * 16 + c;           /* t mod F */                      \
+                const int ip_ = (PER) * F + tp_ - PAD;     /* i (exact in the peeled periods) */ \
+                if ((PER) < 2 && ip_ < 0) {                                                  \
+                    /* dummy step in front of the row */                                     \
+                } else if (t0c_ + c < total) {                                               \
+                    const float e_ = tE[lane][c];                                            \
+                    if ((PER) < 2 && ip_ < KS)                                               \
                         s += (double)e_;                                                     \
-                    } else {                                                                 \
-                        const float l_ = ring[lane][(i - ks) & (kRing - 1)];                 \
-                        s += (double)e_ - (double)l_;                                        \
-                    }                                                                        \
-                    const int o = i - ks + 1; /* output column whose RowSum s now is */      \
-                    if (o >= 0 && (o & (kSB - 1)) == 0 && row_ok)                            \
-                        ST[(size_t)(o >> 4) * h + row0 + lane] = s;                          \
+                    else                                                                     \
+                        s += (double)e_ - (double)fifo[(tp_ + F - (KS % F)) % F];            \
+                    fifo[tp_] = e_;                                                          \
+                    const int o_ = t0c_ + c - PAD - KS + 1; /* output column of this RowSum */ \
+                    if (o_ >= 0 && (o_ & (kSB - 1)) == 0 && row_ok)                          \
+                        ST[(size_t)(o_ >> 4) * h] = s;                                       \
                 }                                                                            \
             }                                                                                \
         }                                                                                    \
     } while (0)
-    RF_RS_FETCH(0, 0);
-    RF_RS_FETCH(1, 16);
-    RF_RS_FETCH(2, 32);
-    RF_RS_FETCH(3, 48);
-    for (int i0 = 0; i0 < total; i0 += 16 * kDepth) {
-        RF_RS_CHUNK(0, i0);
-        RF_RS_CHUNK(1, i0 + 16);
-        RF_RS_CHUNK(2, i0 + 32);
-        RF_RS_CHUNK(3, i0 + 48);
-    }
+#define RF_RS_PERIOD(PER, t0_)                                                               \
+    do {                                                                                     \
+        RF_RS_CHUNK(PER, 0, (t0_));                                                          \
+        RF_RS_CHUNK(PER, 1, (t0_) + 16);                                                     \
+        RF_RS_CHUNK(PER, 2, (t0_) + 32);                                                     \
+        RF_RS_CHUNK(PER, 3, (t0_) + 48);                                                     \
+        RF_RS_CHUNK(PER, 4, (t0_) + 64);                                                     \
+        RF_RS_CHUNK(PER, 5, (t0_) + 80);                                                     \
+        if constexpr (NCH > 6)                                                               \
+            RF_RS_CHUNK(PER, 6, (t0_) + 96);                                                 \
+    } while (0)
+    static_assert(NCH == 6 || NCH == 7, "period of 96 or 112 steps");
+    RF_RS_FETCH(0);
+    RF_RS_PERIOD(0, 0);
+    RF_RS_PERIOD(1, F);
+    for (int t0 = 2 * F; t0 < total; t0 += F)
+        RF_RS_PERIOD(2, t0);
+#undef RF_RS_PERIOD
 #undef RF_RS_CHUNK
 #undef RF_RS_FETCH
 }
@@ -973,8 +979,12 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
             }
             const int row_blocks = ceil_div(h, kBRows);
             if (fused) {
-                hipLaunchKernelGGL(gf_rowstate_kernel, dim3((unsigned)(m * np * row_blocks)), dim3(64),
-                                   0, stream, ab, rows, h, w, radius, row_blocks, np, colour, np, nb);
+                if (radius == 45)
+                    hipLaunchKernelGGL((gf_rowstate_kernel<45>), dim3((unsigned)(m * np * row_blocks)),
+                                       dim3(64), 0, stream, ab, rows, h, w, row_blocks, np, colour, np, nb);
+                else
+                    hipLaunchKernelGGL((gf_rowstate_kernel<52>), dim3((unsigned)(m * np * row_blocks)),
+                                       dim3(64), 0, stream, ab, rows, h, w, row_blocks, np, colour, np, nb);
                 const int it3 = m * 3 * nb, it1 = m * nb;
                 const dim3 g3(8 * (unsigned)ceil_div(it3, 8)), g1(8 * (unsigned)ceil_div(it1, 8));
 #define RF_GF_WALK(R, TT)                                                                             \
