@@ -196,7 +196,7 @@ __global__ __launch_bounds__(kAThreads) void gf_stage1_kernel(
     __shared__ uint32_t wave_tot[NQ][kAWaves];
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int out_w = kACW - 2 * radius;
     const int xs = blockIdx.x * out_w;
     const int ys = blockIdx.y * seg_rows;
@@ -254,9 +254,13 @@ __global__ __launch_bounds__(kAThreads) void gf_stage1_kernel(
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
+            // totals of the waves to the left: all read unconditionally (broadcast reads, issued
+            // together) and selected with the wave-uniform index - a loop over `wave` here becomes
+            // a divergent loop with one exposed LDS round trip per iteration and quantity
             uint32_t base = 0;
-            for (int wv = 0; wv < wave; wv++)
-                base += wave_tot[q][wv];
+#pragma unroll
+            for (int wv = 0; wv < kAWaves - 1; wv++)
+                base += wv < wave ? wave_tot[q][wv] : 0u;
             const uint32_t p1 = incl[q] + base;
             pfx[q][tid * kACols + 2] = p1;
             pfx[q][tid * kACols + 1] = p1 - V[1][q];
