@@ -1639,6 +1639,117 @@ __global__ __launch_bounds__(256) void jbf_f32_kernel(
         dst[(img + (size_t)y * w + x) * SCN + c] = __fmul_rn(sum[c], inv);
 }
 
+
+// Register-tiled CV_32F kernel.  A float texel is 4*(JCN+SCN) bytes, so the (tile + 2r)^2 halo
+// tile of the 8-bit kernels does not fit LDS for 3-channel images at the reference's radius; the
+// texels therefore come through the vector cache, but each lane owns 4 horizontally adjacent
+// outputs (one texel load feeds 4 outputs, lanes of a wave cover 64 contiguous pixels of 4 rows),
+// the interpolated colour table and the spatial weight rows live in LDS, the spatial weights of a
+// lane's 4 outputs slide through registers (one LDS read per column step), columns outside the
+// disk carry weight 0 (adds +0 to the sums: the tap order per output is OpenCV's), and tiles
+// away from the image border skip borderInterpolate.  Same float operations per tap as
+// jbf_f32_kernel, so the values are identical.
+constexpr int kF32TileW = 64, kF32TileH = 16;
+
+template <int JCN, int SCN>
+__global__ __launch_bounds__(256) void jbf_f32_quad_kernel(
+    const float *__restrict__ joint, const float *__restrict__ src, float *__restrict__ dst, int h,
+    int w, int border, const float *__restrict__ luts, int lut_stride,
+    const float *__restrict__ scales, const float *__restrict__ swsym, int sw_len, int r4,
+    int radius, const int *__restrict__ hwtab)
+{
+    extern __shared__ __align__(16) float f32_smem[];
+    float *lut_s = f32_smem;                       // [lut_stride]
+    float *sw_s = f32_smem + ((lut_stride + 3) & ~3);  // [(radius + 1) * sw_len]
+    const int tid = threadIdx.x;
+    {
+        const float *lut = luts + (size_t)blockIdx.z * lut_stride;
+        for (int i = tid; i < lut_stride; i += 256)
+            lut_s[i] = lut[i];
+        for (int i = tid; i < (radius + 1) * sw_len; i += 256)
+            sw_s[i] = swsym[i];
+    }
+    __syncthreads();
+    const int lx = tid & 15, ly = tid >> 4;
+    const int tx0 = blockIdx.x * kF32TileW, ty0 = blockIdx.y * kF32TileH;
+    const int x0 = tx0 + 4 * lx, y = min(ty0 + ly, h - 1);
+    const size_t img = (size_t)blockIdx.z * h * w;
+    const float scale_index = scales[blockIdx.z];
+    // a tile whose taps all fall inside the image needs no border handling
+    const bool interior = tx0 - r4 - 4 >= 0 && tx0 + kF32TileW + r4 + 8 <= w && ty0 - radius >= 0 &&
+                          ty0 + kF32TileH + radius <= h;
+    float j0[4][JCN];
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const int xc = min(x0 + p, w - 1);
+#pragma unroll
+        for (int c = 0; c < JCN; c++)
+            j0[p][c] = joint[(img + (size_t)y * w + xc) * JCN + c];
+    }
+    float sum[4][SCN], wsum[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        wsum[p] = 0.f;
+#pragma unroll
+        for (int c = 0; c < SCN; c++)
+            sum[p][c] = 0.f;
+    }
+    for (int i = -radius; i <= radius; i++) {
+        const int hw = hwtab[i + radius];
+        const int hw4 = (hw + 3) & ~3;
+        const int yy = interior ? y + i : border_interpolate(y + i, h, border);
+        const float *jrow = joint + (img + (size_t)yy * w) * JCN;
+        const float *srow = src + (img + (size_t)yy * w) * SCN;
+        const float *wrow = sw_s + (i < 0 ? -i : i) * sw_len + (r4 + 8);  // wrow[j], zero off the disk
+        // weights of outputs 0..3 at column step c are wrow[c], wrow[c-1], wrow[c-2], wrow[c-3]
+        float w0 = wrow[-hw4], w1 = wrow[-hw4 - 1], w2 = wrow[-hw4 - 2], w3 = wrow[-hw4 - 3];
+        for (int c = -hw4; c <= hw4 + 3; c++) {
+            const int xx = interior ? x0 + c : border_interpolate(x0 + c, w, border);
+            float jt[JCN], st[SCN];
+#pragma unroll
+            for (int ch = 0; ch < JCN; ch++)
+                jt[ch] = jrow[(size_t)xx * JCN + ch];
+#pragma unroll
+            for (int ch = 0; ch < SCN; ch++)
+                st[ch] = srow[(size_t)xx * SCN + ch];
+            const float wnext = wrow[c + 1];
+            const float ws[4] = {w0, w1, w2, w3};
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                float alpha = 0.f;
+#pragma unroll
+                for (int ch = 0; ch < JCN; ch++)
+                    alpha = __fadd_rn(alpha, fabsf(__fsub_rn(j0[p][ch], jt[ch])));
+                alpha = __fmul_rn(alpha, scale_index);
+                const int idx = (int)alpha;
+                alpha = __fsub_rn(alpha, (float)idx);
+                const float l0 = lut_s[idx], l1 = lut_s[idx + 1];
+                const float wgt =
+                    __fmul_rn(ws[p], __fadd_rn(l0, __fmul_rn(alpha, __fsub_rn(l1, l0))));
+#pragma unroll
+                for (int ch = 0; ch < SCN; ch++)
+                    sum[p][ch] = __fadd_rn(sum[p][ch], __fmul_rn(wgt, st[ch]));
+                wsum[p] = __fadd_rn(wsum[p], wgt);
+            }
+            w3 = w2;
+            w2 = w1;
+            w1 = w0;
+            w0 = wnext;
+        }
+    }
+    if (ty0 + ly >= h)
+        return;
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        if (x0 + p >= w)
+            continue;
+        const float inv = __fdiv_rn(1.0f, wsum[p]);
+#pragma unroll
+        for (int c = 0; c < SCN; c++)
+            dst[(img + (size_t)y * w + x0 + p) * SCN + c] = __fmul_rn(sum[p][c], inv);
+    }
+}
+
 }  // namespace
 
 void jbf_shutdown()
@@ -1886,10 +1997,23 @@ extern "C" int rf_jbf_f32(const float *joint, const float *src, float *dst, int 
     }
     RF_HIP_CHECK(hipMemcpy(d_scale, scales.data(), scales.size() * 4, hipMemcpyHostToDevice));
     RF_HIP_CHECK(hipMemcpy(d_luts, luts.data(), luts.size() * 4, hipMemcpyHostToDevice));
+    // register-tiled kernel when its LDS tables fit (always at the reference's radius); the
+    // one-thread-per-pixel kernel otherwise, and as the cross-check (debug option jbf_f32_untiled)
+    const size_t quad_lds = (size_t)(((bins + 2 + 3) & ~3) + (radius + 1) * t.sw_len) * sizeof(float);
+    const bool quad = quad_lds <= 64 * 1024 && !debug_get(kDbgJbfF32Untiled);
     dim3 grid(ceil_div(w, 64), ceil_div(h, 4), n);
+    dim3 gridq(ceil_div(w, kF32TileW), ceil_div(h, kF32TileH), n);
 #define RF_F32(J_, S_)                                                                         \
-    hipLaunchKernelGGL((jbf_f32_kernel<J_, S_>), grid, dim3(256), 0, stream, joint, src, dst, h, w, \
-                       border, d_luts, bins + 2, d_scale, t.d_di, t.d_dj, t.d_sw, t.maxk)
+    do {                                                                                       \
+        if (quad)                                                                              \
+            hipLaunchKernelGGL((jbf_f32_quad_kernel<J_, S_>), gridq, dim3(256), quad_lds, stream, \
+                               joint, src, dst, h, w, border, d_luts, bins + 2, d_scale,       \
+                               t.d_swsym, t.sw_len, t.r4, radius, t.d_hw);                     \
+        else                                                                                   \
+            hipLaunchKernelGGL((jbf_f32_kernel<J_, S_>), grid, dim3(256), 0, stream, joint, src, \
+                               dst, h, w, border, d_luts, bins + 2, d_scale, t.d_di, t.d_dj,   \
+                               t.d_sw, t.maxk);                                                \
+    } while (0)
     if (joint_cn == 3 && src_cn == 3)
         RF_F32(3, 3);
     else if (joint_cn == 3)

@@ -84,6 +84,13 @@ def test_gpu_jbf_f32_bitwise(gpu, jcn, scn):
                                          d, sc, ss, border=border).cpu().numpy()[0]
         want = co.joint_bilateral_filter_f32(joint, src, d, sc, ss, border=border)
         assert np.array_equal(got, want.reshape(got.shape)), (d, sc, ss, border)
+        # the register-tiled kernel (default) against the one-thread-per-pixel kernel
+        with rf._ffi.debug_options(jbf_f32_untiled=1):
+            ref = rf.ops.joint_bilateral_f32(
+                torch.from_numpy(np.ascontiguousarray(joint[None])).cuda(),
+                torch.from_numpy(np.ascontiguousarray(src[None])).cuda(), d, sc, ss,
+                border=border).cpu().numpy()[0]
+        assert np.array_equal(got, ref), (d, sc, ss, border)
 
 
 @pytest.mark.gpu
@@ -168,3 +175,23 @@ def test_guided_filter_ddepth(gpu):
     assert mixed.dtype == np.float32 and np.array_equal(mixed, want_q)
     with pytest.raises(ValueError):
         rf.ximgproc.guidedFilter(guide, src, 9, 3.0, dDepth=2)
+
+
+@pytest.mark.gpu
+def test_gpu_jbf_f32_reference_radius_interior_tiles(gpu):
+    """sigma_s = 22 (radius 33) on an image large enough for interior tiles (no border handling)
+    next to border tiles, three-channel and single-channel: tiled == untiled == oracle on a crop."""
+    rf, torch = gpu
+    h, w = 150, 330
+    joint = _f(synth.scene_u8(h, w, seed=21))
+    src = _f(synth.scene_u8(h, w, seed=22))
+    for jc, sc_ in ((3, 3), (1, 1)):
+        j = np.ascontiguousarray(joint[:, :, :jc])
+        s_ = np.ascontiguousarray(src[:, :, :sc_])
+        jd, sd = torch.from_numpy(j[None]).cuda(), torch.from_numpy(s_[None]).cuda()
+        got = rf.ops.joint_bilateral_f32(jd, sd, -1, 20 / 255.0, 22.0).cpu().numpy()[0]
+        with rf._ffi.debug_options(jbf_f32_untiled=1):
+            ref = rf.ops.joint_bilateral_f32(jd, sd, -1, 20 / 255.0, 22.0).cpu().numpy()[0]
+        assert np.array_equal(got, ref)
+        want = co.joint_bilateral_filter_f32(j, s_, -1, 20 / 255.0, 22.0)
+        assert np.array_equal(got, want.reshape(got.shape))
