@@ -929,7 +929,9 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
     hipStream_t stream = (hipStream_t)stream_;
     // fused stage 2 (row states + column walk) for the instantiated radii; the debug option
     // "gf_two_kernel" forces the row-sum / column-sum kernel pair (cross-check of tests and tools)
-    const bool fused = !debug_get(kDbgGfTwoKernel) && (radius == 45 || radius == 52);
+    // (the fused kernels index a plane with 32-bit offsets: images up to 2^30 pixels)
+    const bool fused = !debug_get(kDbgGfTwoKernel) && (radius == 45 || radius == 52) &&
+                       npx <= ((size_t)1 << 30);
     const int nb = ceil_div(w, kSB);
     const size_t per_img_fused = (size_t)np * (npx * sizeof(float) + (size_t)nb * h * sizeof(double));
     const size_t per_img_used = fused ? per_img_fused : per_img;

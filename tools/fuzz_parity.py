@@ -71,6 +71,13 @@ def main():
             one = rf.ops.guided_filter_u8(scene, col[..., ch:ch + 1].contiguous(), r, eps,
                                           iterations=iters)
             ok = ok and torch.equal(c3[..., ch:ch + 1], one)
+        if r in (45, 52):   # fused stage 2 (default for these radii) against the two-kernel form
+            with _ffi.debug_options(gf_two_kernel=1):
+                ok = ok and torch.equal(g3, rf.ops.guided_filter_u8(scene, grey3, r, eps,
+                                                                    iterations=iters))
+                ok = ok and torch.equal(c3, rf.ops.guided_filter_u8(scene, col, r, eps,
+                                                                    iterations=iters))
+            stats["gf_fused_vs_two_kernel"] = stats.get("gf_fused_vs_two_kernel", 0) + 1
         stats["gf_cases"] += 1
         stats["gf_pixels"] += n * h * w
         if not ok:
