@@ -64,9 +64,24 @@ def main():
     out["gf_f32_1080p"] = {"ms": ms, "mp_per_s": nf * hf * wf / 1e6 / (ms * 1e-3), "batch": nf}
     ms = timed(torch, lambda: rf.ops.joint_bilateral_f32(jf[:1], sf[:1], -1, 20 / 255.0, 22.0), reps=2)
     out["jbf_f32_1080p"] = {"ms": ms, "mp_per_s": hf * wf / 1e6 / (ms * 1e-3), "batch": 1,
-                            "note": "untiled per-pixel kernel, includes the host round trip for "
-                                    "the value range and the table upload"}
+                            "note": "register-tiled kernel, includes the host round trip for the "
+                                    "value range and the table upload"}
     del sc_u8, gr_u8, jf, sf
+    torch.cuda.empty_cache()
+
+    # IIW-size guided filter with the reference's two parameter sets (the README's "0.08 s per
+    # image" case): 256 x 500x333, self-guided c7 s52 and flat-guided c3 s45 on the grey CNN map
+    n, h, w = args.cnn_batch, 333, 500
+    scene, grey = bench.synth_batch(torch, n, h, w, 5004, dev)
+    flat = bench.flat_guide(scene)
+    dst = torch.empty_like(grey)
+    for tag, guide, src, radius, eps in (("gf_iiw_c7s52_self", scene, scene, 52, 7.0),
+                                        ("gf_iiw_c3s45_flat_grey", flat, grey, 45, 3.0)):
+        d2 = torch.empty_like(src)
+        ms = timed(torch, lambda: rf.ops.guided_filter_u8(guide, src, radius, eps, out=d2))
+        out[tag] = {"ms": ms, "batch": n, "mp_per_s": n * h * w / 1e6 / (ms * 1e-3),
+                    "ms_per_image": ms / n}
+    del scene, grey, flat, dst, d2
     torch.cuda.empty_cache()
 
     # C1-size guided filter, single image latency
@@ -117,7 +132,7 @@ def main():
         entry["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s",
                              "frac": gbs / 8000.0, "algorithmic_bytes_per_px": bytes_per_px * passes}
     for key, entry in out.items():
-        if key.startswith("gf_4k_x1"):
+        if key.startswith("gf_4k_x1") or key.startswith("gf_iiw"):
             hbm(entry, 9)
         elif key.startswith("gf_4k_x3"):
             hbm(entry, 21)                    # guide read once per pass, u8 hand-offs: 3+3+3, +6, +6
