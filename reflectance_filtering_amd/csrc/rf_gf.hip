@@ -36,9 +36,11 @@ namespace {
 // stage 1 + per-pixel algebra
 // ------------------------------------------------------------------------------------------
 constexpr int kAThreads = 256;
-constexpr int kACols = 2;                      // columns per thread
-constexpr int kACW = kAThreads * kACols;       // strip width incl. halo
 constexpr int kAWaves = kAThreads / 64;
+// columns per thread (strip width incl. halo = 256 x that): 3 for one computed src channel
+// (13 quantities: 40 KB of prefix sums, 4 workgroups per CU; 768-column strips waste less on the
+// 2r-column halo and on the last strip of a 3840-wide image), 2 for three (21 quantities)
+constexpr int stage1_cols(int scn) { return scn == 1 ? 3 : 2; }
 
 template <int SCN>
 struct Quant {
@@ -192,6 +194,8 @@ __global__ __launch_bounds__(kAThreads) void gf_stage1_kernel(
     if (wrong_variant<SCN>(colour, blockIdx.z))
         return;
     constexpr int NQ = Quant<SCN>::NQ;
+    constexpr int kACols = stage1_cols(SCN);
+    constexpr int kACW = kAThreads * kACols;
     __shared__ uint32_t pfx[NQ][kACW + 1];
     __shared__ uint32_t wave_tot[NQ][kAWaves];
 
@@ -246,7 +250,11 @@ __global__ __launch_bounds__(kAThreads) void gf_stage1_kernel(
         uint32_t incl[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
-            const uint32_t s = wave_inclusive_scan(V[0][q] + V[1][q]);
+            uint32_t tsum = V[0][q];
+#pragma unroll
+            for (int k = 1; k < kACols; k++)
+                tsum += V[k][q];
+            const uint32_t s = wave_inclusive_scan(tsum);
             incl[q] = s;
             if (lane == 63)
                 wave_tot[q][wave] = s;
@@ -261,9 +269,12 @@ __global__ __launch_bounds__(kAThreads) void gf_stage1_kernel(
 #pragma unroll
             for (int wv = 0; wv < kAWaves - 1; wv++)
                 base += wv < wave ? wave_tot[q][wv] : 0u;
-            const uint32_t p1 = incl[q] + base;
-            pfx[q][tid * kACols + 2] = p1;
-            pfx[q][tid * kACols + 1] = p1 - V[1][q];
+            uint32_t pk = incl[q] + base;  // inclusive prefix at the thread's last column
+#pragma unroll
+            for (int k = kACols - 1; k >= 0; k--) {
+                pfx[q][tid * kACols + k + 1] = pk;
+                pk -= V[k][q];
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -940,8 +951,10 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
         chunk = 16383;
     const float eps_f = (float)eps;
     const int eps_small = eps < 1e-2;
-    const int out_w = kACW - 2 * radius;
-    const int strips = ceil_div(w, out_w);
+    // stage-1 strips: 256 threads x stage1_cols columns, 2r of them halo
+    const int strips3 = ceil_div(w, kAThreads * stage1_cols(3) - 2 * radius);
+    const int strips1 = ceil_div(w, kAThreads * stage1_cols(1) - 2 * radius);
+    const int strips = src_cn == 3 ? strips3 : strips1;
 
     // 3-channel sources: find the images whose channels are identical (see the file header)
     int *colour_all = nullptr;
@@ -973,14 +986,14 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
         const int segs = ceil_div(h, seg_rows);
         for (int it = 0; it < iterations; it++) {
             const uint8_t *s0 = (it == 0 ? src : (const uint8_t *)dst) + (size_t)i0 * npx * src_cn;
-            dim3 ga(strips, segs, m);
+            const dim3 ga3(strips3, segs, m), ga1(strips1, segs, m);
             if (src_cn == 3) {
-                hipLaunchKernelGGL((gf_stage1_kernel<3, 3>), ga, dim3(kAThreads), 0, stream, g0, s0,
+                hipLaunchKernelGGL((gf_stage1_kernel<3, 3>), ga3, dim3(kAThreads), 0, stream, g0, s0,
                                    ab, h, w, radius, eps_f, eps_small, seg_rows, colour);
-                hipLaunchKernelGGL((gf_stage1_kernel<1, 3>), ga, dim3(kAThreads), 0, stream, g0, s0,
+                hipLaunchKernelGGL((gf_stage1_kernel<1, 3>), ga1, dim3(kAThreads), 0, stream, g0, s0,
                                    ab, h, w, radius, eps_f, eps_small, seg_rows, colour);
             } else {
-                hipLaunchKernelGGL((gf_stage1_kernel<1, 1>), ga, dim3(kAThreads), 0, stream, g0, s0,
+                hipLaunchKernelGGL((gf_stage1_kernel<1, 1>), ga1, dim3(kAThreads), 0, stream, g0, s0,
                                    ab, h, w, radius, eps_f, eps_small, seg_rows, colour);
             }
             const int row_blocks = ceil_div(h, kBRows);
