@@ -8,6 +8,7 @@ import numpy as np
 from . import _ffi
 
 _gf_workspaces = {}
+_GF_CACHE_PER_DEVICE = 4
 _cnn_consts = {}
 
 
@@ -56,12 +57,17 @@ def gf_workspace(n, h, w, scn, radius, device, torch):
     need = lib.rf_gf_workspace_bytes(n, h, w, 3, scn, radius)
     dev = device.index if device.index is not None else torch.cuda.current_device()
     key = (dev, torch.cuda.current_stream(dev).cuda_stream)
-    ws = _gf_workspaces.get(key)
+    ws = _gf_workspaces.pop(key, None)       # re-inserted below: dict order = least recently used first
     if ws is None or ws.numel() < need:
-        _gf_workspaces.pop(key, None)
         ws = None
+        # streams come and go: keep at most _GF_CACHE_PER_DEVICE buffers per device (dropping a
+        # buffer is safe: torch's stream-ordered allocator does not recycle the block before the
+        # stream it was allocated on has passed the work that used it)
+        mine = [k for k in _gf_workspaces if k[0] == dev]
+        for k in mine[:max(0, len(mine) - (_GF_CACHE_PER_DEVICE - 1))]:
+            del _gf_workspaces[k]
         ws = torch.empty(need, dtype=torch.uint8, device=device)
-        _gf_workspaces[key] = ws
+    _gf_workspaces[key] = ws
     return ws
 
 

@@ -632,3 +632,35 @@ def test_captured_call_replays_the_chain(env):
         want_gf = rf.ops.guided_filter_u8(g, s, 9, 3.0, iterations=3)
         want_bf = rf.ops.joint_bilateral_u8(g, s, -1, 20.0, 5.0)
         assert torch.equal(a, want_gf) and torch.equal(b, want_bf), seed
+
+
+def test_two_streams_do_not_share_scratch(env):
+    """Guided-filter workspaces are cached per (device, stream) and the CNN's packed weights live
+    in a per-(device, stream) buffer: calls in flight on two streams give the bytes of the
+    one-stream calls (they used to share planes / one weight buffer per device)."""
+    from tests import synth
+    rf, co, torch = env
+    h, w = 700, 900
+    ga = torch.from_numpy(synth.flat_guide_u8(h, w, seed=1, cells=30)[None]).cuda()
+    gb = torch.from_numpy(synth.scene_u8(h, w, seed=2)[None]).cuda()
+    sa = torch.from_numpy(synth.scene_u8(h, w, seed=3)[None]).cuda()
+    sb = torch.from_numpy(synth.reflectance_like_u8(h, w, seed=4)[None]).cuda()
+    want_a = rf.ops.guided_filter_u8(ga, sa, 45, 3.0, iterations=2)
+    want_b = rf.ops.guided_filter_u8(gb, sb, 45, 3.0, iterations=2)
+    wts = rf.weights.load_weights()
+    wts2 = (wts * np.float32(0.97)).astype(np.float32)
+    want_r1, _ = rf.ops.cnn_reflectance_u8(gb, weights=wts)
+    want_r2, _ = rf.ops.cnn_reflectance_u8(gb, weights=wts2)
+    assert not torch.equal(want_r1, want_r2)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(4):
+        with torch.cuda.stream(s1):
+            a = rf.ops.guided_filter_u8(ga, sa, 45, 3.0, iterations=2)
+            r1, _ = rf.ops.cnn_reflectance_u8(gb, weights=wts)
+        with torch.cuda.stream(s2):
+            b = rf.ops.guided_filter_u8(gb, sb, 45, 3.0, iterations=2)
+            r2, _ = rf.ops.cnn_reflectance_u8(gb, weights=wts2)
+        torch.cuda.synchronize()
+        assert torch.equal(a, want_a) and torch.equal(b, want_b)
+        assert torch.equal(r1, want_r1) and torch.equal(r2, want_r2)
