@@ -664,3 +664,32 @@ def test_two_streams_do_not_share_scratch(env):
         torch.cuda.synchronize()
         assert torch.equal(a, want_a) and torch.equal(b, want_b)
         assert torch.equal(r1, want_r1) and torch.equal(r2, want_r2)
+
+
+@pytest.mark.parametrize("radius,eps", [(45, 3.0), (52, 7.0)])
+def test_gf_fused_stage2_in_place_chain_and_oracle(env, radius, eps):
+    """The fused stage 2 (radius 45 / 52): colour and grey images in one batch, three chained
+    passes, dst aliasing src, a workspace for one image - against the oracle chained three times
+    and against the two-kernel stage 2."""
+    from tests import synth
+    rf, co, torch = env
+    h, w = 210, 333                      # h not a multiple of the sub-tile, w not of 16
+    guide = synth.flat_guide_u8(h, w, seed=radius, cells=25)
+    srcs = [synth.scene_u8(h, w, seed=radius + 1), synth.reflectance_like_u8(h, w, seed=radius + 2)]
+    g = torch.from_numpy(np.stack([guide, guide])).cuda()
+    s = torch.from_numpy(np.stack(srcs)).cuda()
+    want = []
+    for src in srcs:
+        cur = src
+        for _ in range(3):
+            cur = co.guided_filter(guide, cur, radius, eps)
+        want.append(cur)
+    got = rf.ops.guided_filter_u8(g, s, radius, eps, iterations=3)
+    assert np.array_equal(got.cpu().numpy(), np.stack(want))
+    with rf._ffi.debug_options(gf_two_kernel=1):
+        assert torch.equal(rf.ops.guided_filter_u8(g, s, radius, eps, iterations=3), got)
+    one = rf._ffi.load_library().rf_gf_workspace_bytes(1, h, w, 3, 3, radius)
+    ws = torch.empty(one, dtype=torch.uint8, device="cuda")
+    inplace = s.clone()
+    rf.ops.guided_filter_u8(g, inplace, radius, eps, iterations=3, out=inplace, workspace=ws)
+    assert torch.equal(inplace, got)
