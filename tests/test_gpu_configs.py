@@ -117,3 +117,28 @@ def test_c4_512_image_launch(env):
                                          20.0, 22.0)
         got = out[img, y0:y0 + 70, x0:x0 + 90].cpu().numpy()
         assert np.array_equal(got, want[y0 - ya:y0 - ya + 70, x0 - xa:x0 - xa + 90]), img
+
+
+def test_c5_full_shard_128_images(env):
+    """One rank's C5 shard at its stated size: 128 x 3840x2160 through three guided passes in ONE
+    call (the workspace holds a dozen images, so the call runs in chunks).  Four distinct images
+    repeated 32 times must give four distinct results repeated 32 times, equal to the one-image
+    calls (which test_c5_4k_three_guided_passes_against_oracle ties to the oracle)."""
+    rf, co, torch, bench = env
+    dev = torch.device("cuda", 0)
+    scene4, grey4 = bench.synth_batch(torch, 4, 2160, 3840, 7200, dev)
+    guide4 = bench.flat_guide(scene4)
+    src4 = grey4.clone()
+    src4[3] = scene4[3]                       # one colour source among the grey ones
+    guide = guide4.repeat(32, 1, 1, 1)
+    src = src4.repeat(32, 1, 1, 1)
+    assert guide.shape == (128, 2160, 3840, 3)
+    out = rf.ops.guided_filter_u8(guide, src, 45, 3.0, iterations=3)
+    for i in range(4):
+        one = rf.ops.guided_filter_u8(guide4[i:i + 1].contiguous(), src4[i:i + 1].contiguous(), 45,
+                                      3.0, iterations=3)
+        for k in range(32):
+            assert torch.equal(out[4 * k + i], one[0]), (i, k)
+    del out, guide, src
+    rf.ops.release_workspaces()
+    torch.cuda.empty_cache()
