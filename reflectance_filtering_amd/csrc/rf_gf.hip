@@ -611,6 +611,7 @@ __global__ __launch_bounds__(64) void gf_colwalk_kernel(
     __shared__ float stE[4 * T][kSB + 1], stL[4 * T][kSB + 1]; // operands [plane*T + row][col]
     __shared__ float xch[T][4][kSB];                          // means of the sub-tile's rows
     __shared__ int rowtab[2][T + 1];                          // image row of each padded row
+    __shared__ uint32_t rowoff[2][T + 1];                     // ... times 4 w (byte offset of the row in a plane)
     __shared__ uint32_t gst[T][12];                           // guide bytes of the output rows
 
     const int lane = threadIdx.x;
@@ -624,8 +625,14 @@ __global__ __launch_bounds__(64) void gf_colwalk_kernel(
     const uint8_t *gimg = guide + (size_t)img * npx * 3;
     uint8_t *dimg = dst + (size_t)img * npx * SPX;
     // RowSum at output column o = 16 b + cc (cc >= 1):  + ext[o + 2r] - ext[o - 1], ext[i] = S[bi(i - r)]
-    const float *Pe = abg + (size_t)g4 * npx + border_interpolate(b * kSB + cc + R, w, RF_BORDER_REFLECT);
-    const float *Pl = abg + (size_t)g4 * npx + border_interpolate(b * kSB + cc - 1 - R, w, RF_BORDER_REFLECT);
+    // per-lane element offsets from the wave-uniform base abg (32 bits: the host admits images of
+    // less than 2^28 pixels here, so 4 planes stay below 2^30 elements); rowtab holds row * w
+    // (BYTE offsets, so that base + zero-extended offset is the whole address computation)
+    const uint32_t oe = 4u * ((uint32_t)g4 * (uint32_t)npx +
+                              (uint32_t)border_interpolate(b * kSB + cc + R, w, RF_BORDER_REFLECT));
+    const uint32_t ol = 4u * ((uint32_t)g4 * (uint32_t)npx +
+                              (uint32_t)border_interpolate(b * kSB + cc - 1 - R, w, RF_BORDER_REFLECT));
+    const char *abgb = reinterpret_cast<const char *>(abg);
     const double *Ps = stg + ((size_t)min(cp, 3) * nb + b) * h;
     const double scale = 1.0 / (double)(KS * KS);
     const int nsub = (h + 2 * R + T - 1) / T;  // > NSUB
@@ -638,17 +645,20 @@ __global__ __launch_bounds__(64) void gf_colwalk_kernel(
     /* padded row -> image row (BORDER_REFLECT) */
 #define RF_ROWTAB(u_)                                                                        \
     do {                                                                                     \
-        if (lane < T)                                                                        \
-            rowtab[(u_) & 1][lane] = border_interpolate(min((u_) * T + lane, jmax) - R, h,   \
-                                                        RF_BORDER_REFLECT);                  \
+        if (lane < T) {                                                                      \
+            const int row_ = border_interpolate(min((u_) * T + lane, jmax) - R, h,           \
+                                                RF_BORDER_REFLECT);                          \
+            rowtab[(u_) & 1][lane] = row_;                                                   \
+            rowoff[(u_) & 1][lane] = 4u * (uint32_t)row_ * (uint32_t)w;                      \
+        }                                                                                    \
     } while (0)
 #define RF_FETCH(u_)                                                                         \
     do {                                                                                     \
         _Pragma("unroll") for (int L = 0; L < T; L++)                                        \
         {                                                                                    \
-            const uint32_t ro_ = (uint32_t)rowtab[(u_) & 1][L] * (uint32_t)w;                \
-            pe[L] = Pe[ro_];                                                                 \
-            pl[L] = Pl[ro_];                                                                 \
+            const uint32_t ro_ = rowoff[(u_) & 1][L];                                        \
+            pe[L] = *reinterpret_cast<const float *>(abgb + (oe + ro_));                     \
+            pl[L] = *reinterpret_cast<const float *>(abgb + (ol + ro_));                     \
         }                                                                                    \
         if (chain)                                                                           \
             pst = Ps[rowtab[(u_) & 1][cl]];                                                  \
@@ -940,9 +950,9 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
     hipStream_t stream = (hipStream_t)stream_;
     // fused stage 2 (row states + column walk) for the instantiated radii; the debug option
     // "gf_two_kernel" forces the row-sum / column-sum kernel pair (cross-check of tests and tools)
-    // (the fused kernels index a plane with 32-bit offsets: images up to 2^30 pixels)
+    // (the fused kernels index planes with 32-bit element offsets: images below 2^28 pixels)
     const bool fused = !debug_get(kDbgGfTwoKernel) && (radius == 45 || radius == 52) &&
-                       npx <= ((size_t)1 << 30);
+                       npx < ((size_t)1 << 28);
     const int nb = ceil_div(w, kSB);
     const size_t per_img_fused = (size_t)np * (npx * sizeof(float) + (size_t)nb * h * sizeof(double));
     const size_t per_img_used = fused ? per_img_fused : per_img;
