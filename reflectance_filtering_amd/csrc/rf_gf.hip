@@ -702,25 +702,35 @@ __global__ __launch_bounds__(64) void gf_colwalk_kernel(
         if (uu_ + 1 < nsub)                                                                  \
             RF_FETCH(uu_ + 1);                                                               \
         if (chain) {                                                                         \
+            /* all operand differences first (independent LDS reads and conversions), then   */ \
+            /* the chain of dependent adds: the wave is alone on its SIMD, nothing else hides */ \
+            /* an LDS round trip per step                                                     */ \
+            double d_[kSB];                                                                  \
+            _Pragma("unroll") for (int c = 1; c < kSB; c++)                                  \
+                d_[c] = (double)stE[lane][c] - (double)stL[lane][c];                         \
             Rt[cp * kSB][cl] = s_;                                                           \
             _Pragma("unroll") for (int c = 1; c < kSB; c++)                                  \
             {                                                                                \
-                s_ += (double)stE[lane][c] - (double)stL[lane][c];                           \
+                s_ += d_[c];                                                                 \
                 Rt[cp * kSB + c][cl] = s_;                                                   \
             }                                                                                \
         }                                                                                    \
         __syncthreads();                                                                     \
-        _Pragma("unroll") for (int jj = 0; jj < T; jj++)                                     \
         {                                                                                    \
-            const double v_ = Rt[lane][jj];                                                  \
-            if (FILL) {                                                                      \
-                SUM += v_;                                                                   \
-            } else {                                                                         \
-                const double s0_ = SUM + v_;                                                 \
-                xch[jj][g4][cc] = (float)(s0_ * scale);                                      \
-                SUM = s0_ - fifo[(KSLOT) * T + jj];                                          \
+            /* the sub-tile's row sums first (independent LDS reads), then the dependent chain */ \
+            double v_[T];                                                                    \
+            _Pragma("unroll") for (int jj = 0; jj < T; jj++) v_[jj] = Rt[lane][jj];          \
+            _Pragma("unroll") for (int jj = 0; jj < T; jj++)                                 \
+            {                                                                                \
+                if (FILL) {                                                                  \
+                    SUM += v_[jj];                                                           \
+                } else {                                                                     \
+                    const double s0_ = SUM + v_[jj];                                         \
+                    xch[jj][g4][cc] = (float)(s0_ * scale);                                  \
+                    SUM = s0_ - fifo[(KSLOT) * T + jj];                                      \
+                }                                                                            \
+                fifo[(KSLOT) * T + jj] = v_[jj];                                             \
             }                                                                                \
-            fifo[(KSLOT) * T + jj] = v_;                                                     \
         }                                                                                    \
         if (!(FILL)) {                                                                       \
             _Pragma("unroll") for (int k = 0; k < NG; k++)                                   \
@@ -731,25 +741,32 @@ __global__ __launch_bounds__(64) void gf_colwalk_kernel(
             }                                                                                \
             __syncthreads();                                                                 \
             const int y0_ = (uu_ - NSUB) * T;                                                \
+            /* NF independent pixels per lane, computed branch-free so that their LDS reads and */ \
+            /* dependent float chains overlap (one wave per SIMD: nobody else hides them);      */ \
+            /* only the stores are predicated                                                   */ \
+            uint8_t o_[NF];                                                                  \
             _Pragma("unroll") for (int k = 0; k < NF; k++)                                   \
             {                                                                                \
-                const int idx_ = lane + 64 * k;                                              \
-                const int fr_ = idx_ >> 4;                                                   \
+                const int fr_ = min((lane + 64 * k) >> 4, T - 1);                            \
+                const uint8_t *gb_ = reinterpret_cast<const uint8_t *>(&gst[fr_][0]) + 3 * cc; \
+                float q_ = xch[fr_][3][cc];                                                  \
+                q_ = __fadd_rn(q_, __fmul_rn(xch[fr_][0][cc], (float)gb_[0]));               \
+                q_ = __fadd_rn(q_, __fmul_rn(xch[fr_][1][cc], (float)gb_[1]));               \
+                q_ = __fadd_rn(q_, __fmul_rn(xch[fr_][2][cc], (float)gb_[2]));               \
+                o_[k] = saturate_u8(q_);                                                     \
+            }                                                                                \
+            _Pragma("unroll") for (int k = 0; k < NF; k++)                                   \
+            {                                                                                \
+                const int fr_ = (lane + 64 * k) >> 4;                                        \
                 const int y_ = y0_ + fr_, x_ = b * kSB + cc;                                 \
                 if (fr_ < T && y_ < h && x_ < w) {                                           \
                     const uint32_t pix_ = (uint32_t)y_ * w + x_;                             \
-                    const uint8_t *gb_ = reinterpret_cast<const uint8_t *>(&gst[fr_][0]) + 3 * cc; \
-                    float q_ = xch[fr_][3][cc];                                              \
-                    q_ = __fadd_rn(q_, __fmul_rn(xch[fr_][0][cc], (float)gb_[0]));           \
-                    q_ = __fadd_rn(q_, __fmul_rn(xch[fr_][1][cc], (float)gb_[1]));           \
-                    q_ = __fadd_rn(q_, __fmul_rn(xch[fr_][2][cc], (float)gb_[2]));           \
-                    const uint8_t o_ = saturate_u8(q_);                                      \
                     if (SCN == SPX) {                                                        \
-                        dimg[(size_t)pix_ * SCN + s_ch] = o_;                                \
+                        dimg[(size_t)pix_ * SCN + s_ch] = o_[k];                             \
                     } else { /* grey image: the computed channel stands for all three */     \
-                        dimg[(size_t)pix_ * 3 + 0] = o_;                                     \
-                        dimg[(size_t)pix_ * 3 + 1] = o_;                                     \
-                        dimg[(size_t)pix_ * 3 + 2] = o_;                                     \
+                        dimg[(size_t)pix_ * 3 + 0] = o_[k];                                  \
+                        dimg[(size_t)pix_ * 3 + 1] = o_[k];                                  \
+                        dimg[(size_t)pix_ * 3 + 2] = o_[k];                                  \
                     }                                                                        \
                 }                                                                            \
             }                                                                                \
