@@ -53,6 +53,14 @@ def main():
     a = rf.ops.guided_filter_u8(small_j, small_s, 2, 3.0)
     b = rf.ops.guided_filter_u8(small_j[idx].contiguous(), small_s[idx].contiguous(), 2, 3.0)
     res["gf_70000_small"] = bool(torch.equal(a[idx], b))
+    # the fused stage 2 (radius 45) on the same 70,000 tiny images: 210,000 single-wave work items
+    # whose every tap is a reflected border pixel; colour sources and, in a second call, grey ones
+    a = rf.ops.guided_filter_u8(small_j, small_s, 45, 3.0, iterations=2)
+    b = rf.ops.guided_filter_u8(small_j[idx].contiguous(), small_s[idx].contiguous(), 45, 3.0,
+                                iterations=2)
+    a2 = rf.ops.guided_filter_u8(small_s, small_j, 45, 3.0)
+    b2 = rf.ops.guided_filter_u8(small_s[idx].contiguous(), small_j[idx].contiguous(), 45, 3.0)
+    res["gf_fused_70000_small"] = bool(torch.equal(a[idx], b) and torch.equal(a2[idx], b2))
     r, _ = rf.get_reflectance_batch(small_j)
     refl, shad = rf.ops.colorize_srgb_u8(small_j[:60000].contiguous(), r[:60000].contiguous())
     refl2, shad2 = rf.ops.colorize_srgb_u8(small_j[idx[:2]].contiguous(), r[idx[:2]].contiguous())
