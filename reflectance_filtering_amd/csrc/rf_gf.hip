@@ -15,7 +15,11 @@
 //            border-extended row starting at its left end, ColumnSum<double,float> a running
 //            sum down the image starting 2r rows above the first output row.  Both are
 //            reproduced as sequential chains (one lane per row / per column), exposed to the
-//            GPU as parallelism over rows x planes x images.  -> gf_rowsum_kernel, gf_colsum_apply_kernel
+//            GPU as parallelism over rows x planes x images, in two forms with identical bytes:
+//            radius 45 / 52 (the reference's parameter sets): gf_rowstate_kernel +
+//            gf_colwalk_kernel - the double row sums never reach HBM (see the comment block
+//            above them); any other radius <= 120: gf_rowsum_kernel + gf_colsum_apply_kernel,
+//            which write every row sum (8 B per pixel and plane) and read it twice.
 //
 // Grey sources: the reference filters the CNN's grey `-r.png`, which imread turns into three
 // identical channels.  The src channels never mix, so identical channels give identical
@@ -26,8 +30,6 @@
 #include "rf_common.hpp"
 
 #include <algorithm>
-#include <cstdlib>
-#include <type_traits>
 
 namespace rf {
 namespace {
@@ -457,20 +459,19 @@ __global__ __launch_bounds__(64 * 4 * SCN) void gf_colsum_apply_kernel(
 //                        same RowSum<float,double> chain as gf_rowsum_kernel) but stores the
 //                        running sum only at every 16th column: states[plane][x/16][row].
 //   gf_colwalk_kernel    one wave owns 16 columns x the 4 planes (alpha_0..2, beta) of one src
-//                        channel and walks down the image in tiles of R rows.  Row phase (lane =
-//                        row): restart the row chain of each plane from the stored state and
-//                        rebuild the tile's R x 16 row sums in LDS.  Column phase (lane = plane x
-//                        column): ColumnSum<double,float> down the tile; the value leaving the
-//                        window, R[y - r], is the value that entered 2r steps earlier in the same
-//                        lane, so it is kept in a register FIFO of 2r doubles (statically indexed:
-//                        the loop body is two tiles of R rows, fully unrolled).  Every four rows
-//                        the four means of a pixel meet in LDS and q = beta + sum alpha_g I_g is
-//                        formed and stored.
+//                        channel and walks down the image in sub-tiles of T rows (2R = NSUB T).
+//                        Row phase (lane = plane x row): restart each row chain from its stored
+//                        state and rebuild the sub-tile's T x 16 row sums in LDS.  Column phase
+//                        (lane = plane x column): ColumnSum<double,float> down the sub-tile; the
+//                        value leaving the window, R[y - r], is the value that entered 2r steps
+//                        earlier in the same lane, so it is kept in a register FIFO of 2r doubles
+//                        (statically indexed: the loop body is one period of NSUB sub-tiles,
+//                        fully unrolled).  After each sub-tile the four means of a pixel meet in
+//                        LDS and q = beta + sum alpha_g I_g is formed and stored.
 //
 // Every double add happens in the order of the two-kernel form above, so the bytes are the same;
-// HBM traffic of stage 2 drops from  96 (row sums written) + 192 (read as S+ and S-) + 96 (alpha/
-// beta read twice)  to  48 + 96 (alpha/beta read by both kernels, the second read of the walk from
-// L2) bytes per pixel and src channel triple.
+// measured memory-side traffic of a whole pass at 8 x 4K, colour src: 548 -> 215 B/px
+// (profiles/r02base_gf_cnn.md, r02_gf_cnn.md).
 // ------------------------------------------------------------------------------------------
 constexpr int kSB = 16;      // columns per state block and per column-walk wave
 
