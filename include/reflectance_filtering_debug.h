@@ -12,6 +12,8 @@
  *   "jbf_tile64_only"    joint bilateral: no strip tiles at the image remainder; identical bytes
  *   "jbf_tune"           joint bilateral: kernel-variant override 1..7 (tools/jbf_tune.py)
  *   "jbf_f32_untiled"    float joint bilateral: one-thread-per-pixel kernel; identical values
+ *   "cnn_lds_columns"    CNN: activations pass between layers through LDS columns instead of
+ *                        registers; identical values
  *   "jbf_stage_only"     joint bilateral: stage the tile and return WITHOUT WRITING dst
  *                        (tools/jbf_tune.py --stage-only, timing only)
  */

@@ -222,6 +222,191 @@ __global__ __launch_bounds__(kCnnThreads) void cnn_reflectance_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Register-resident form (default): the same FMA chains, no LDS for activations.
+//
+// Activations are kept as one register pair per channel holding {pixel 0, pixel 1}.  The packed FMA
+// of output-channel pair (2o, 2o+1) and pixel p reads its input through op_sel on the VGPR
+// operand (both halves take pixel p's value) - op_sel on a VGPR source is sound on gfx950, only an
+// SGPR source with re-routed halves is not - so inputs are not duplicated; the
+// channel-pair loop is fully unrolled with statically named outputs, and bias + ReLU write the
+// next layer's {pixel 0, pixel 1} pairs directly.  Against the LDS-column form this drops the 32
+// KB of LDS per workgroup, the write/read of every activation through it and the duplicating
+// moves: ~170 VGPRs and nothing else limiting occupancy, i.e. three waves per SIMD instead of two.
+// The layer loop stays rolled (input pairs A, output pairs B, 32 moves B -> A per layer): unrolled,
+// hipcc gives every layer's outputs registers of their own (+64 per layer) and the kernel drops
+// to one wave per SIMD.  Every scalar load is an asm statement at an immediate offset from a
+// per-layer base: plain loads are hoisted together and spill the SGPR file.
+// ------------------------------------------------------------------------------------------
+#define RF_PKFMA_P0(ACC, W2, IN)                                                              \
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]"               \
+                 : "+v"(ACC)                                                                  \
+                 : "s"(W2), "v"(IN))
+#define RF_PKFMA_P1(ACC, W2, IN)                                                              \
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]"               \
+                 : "+v"(ACC)                                                                  \
+                 : "s"(W2), "v"(IN))
+
+// bias + ReLU of one channel pair for both pixels, written as next-layer pairs {px0, px1}
+__device__ __forceinline__ void finish_pair(const float2v &acc0, const float2v &acc1, float bx,
+                                            float by, float2v &out_even, float2v &out_odd)
+{
+    out_even = float2v{fmaxf(__fadd_rn(acc0.x, bx), 0.f), fmaxf(__fadd_rn(acc1.x, bx), 0.f)};
+    out_odd = float2v{fmaxf(__fadd_rn(acc0.y, by), 0.f), fmaxf(__fadd_rn(acc1.y, by), 0.f)};
+}
+
+// A 32-input layer: in[k] = {px0, px1} of input channel k, out[c] likewise.  rec = the layer's 16
+// records of kRec floats (buffer A: k = 0..15 of a channel pair, buffer B: k = 16..31 + biases).
+__device__ __forceinline__ void layer32_regs(const float *__restrict__ rec, const float2v (&in)[32],
+                                             float2v (&out)[32])
+{
+    float16v a0, a1, b0, b1;
+    float2v bias;
+#define RF_SLOAD16(DST, PTR, OFF) \
+    asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(DST) : "s"(PTR), "n"(OFF))
+#define RF_SLOAD2(DST, PTR, OFF) \
+    asm volatile("s_load_dwordx2 %0, %1, %2" : "=s"(DST) : "s"(PTR), "n"(OFF))
+#define RF_FMA16R(W0, W1, KBASE)                                                             \
+    _Pragma("unroll") for (int k = 0; k < 8; k++)                                            \
+    {                                                                                        \
+        const float2v w2 = float2v{W0[2 * k], W0[2 * k + 1]};                                \
+        RF_PKFMA_P0(acc0, w2, in[(KBASE) + k]);                                              \
+        RF_PKFMA_P1(acc1, w2, in[(KBASE) + k]);                                              \
+    }                                                                                        \
+    _Pragma("unroll") for (int k = 0; k < 8; k++)                                            \
+    {                                                                                        \
+        const float2v w2 = float2v{W1[2 * k], W1[2 * k + 1]};                                \
+        RF_PKFMA_P0(acc0, w2, in[(KBASE) + 8 + k]);                                          \
+        RF_PKFMA_P1(acc1, w2, in[(KBASE) + 8 + k]);                                          \
+    }
+    RF_SLOAD16(a0, rec, 0);
+    RF_SLOAD16(a1, rec, 64);
+#define RF_OP(OP)                                                                            \
+    {                                                                                        \
+        constexpr int cur_ = (OP) * kRec * 4;                                                \
+        constexpr int nxt_ = ((OP) < 15 ? (OP) + 1 : (OP)) * kRec * 4;                       \
+        float2v acc0 = float2v{0.f, 0.f}, acc1 = float2v{0.f, 0.f};                          \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1));                           \
+        RF_SLOAD16(b0, rec, cur_ + 128);                                                     \
+        RF_SLOAD16(b1, rec, cur_ + 192);                                                     \
+        RF_SLOAD2(bias, rec, cur_ + 256);                                                    \
+        RF_FMA16R(a0, a1, 0)                                                                 \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b0), "+s"(b1), "+s"(bias));               \
+        RF_SLOAD16(a0, rec, nxt_);                                                           \
+        RF_SLOAD16(a1, rec, nxt_ + 64);                                                      \
+        RF_FMA16R(b0, b1, 16)                                                                \
+        finish_pair(acc0, acc1, bias.x, bias.y, out[2 * (OP)], out[2 * (OP) + 1]);           \
+    }
+    RF_OP(0) RF_OP(1) RF_OP(2) RF_OP(3) RF_OP(4) RF_OP(5) RF_OP(6) RF_OP(7)
+    RF_OP(8) RF_OP(9) RF_OP(10) RF_OP(11) RF_OP(12) RF_OP(13) RF_OP(14) RF_OP(15)
+#undef RF_OP
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1));
+#undef RF_FMA16R
+#undef RF_SLOAD2
+#undef RF_SLOAD16
+}
+
+// 32 terms of the fuse dot product for both pixels
+__device__ __forceinline__ void fuse32(const float2v (&act)[32], const float *__restrict__ wf32,
+                                       float (&z)[kPxPerLane])
+{
+    float16v w0, w1;
+    asm volatile("s_load_dwordx16 %0, %1, 0" : "=s"(w0) : "s"(wf32));
+    asm volatile("s_load_dwordx16 %0, %1, 64" : "=s"(w1) : "s"(wf32));
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(w0), "+s"(w1));
+    // scalar FMAs spelled out: left to the SLP vectoriser the two chains become one v_pk_fma_f32
+    // with the SGPR weight splat through op_sel_hi, the operand form tests/test_cabi.py bans
+    // 
+#define RF_FUSE_FMA(Z, W, X) asm("v_fma_f32 %0, %1, %2, %0" : "+v"(Z) : "s"(W), "v"(X))
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        RF_FUSE_FMA(z[0], w0[k], act[k].x);
+        RF_FUSE_FMA(z[1], w0[k], act[k].y);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        RF_FUSE_FMA(z[0], w1[k], act[16 + k].x);
+        RF_FUSE_FMA(z[1], w1[k], act[16 + k].y);
+    }
+#undef RF_FUSE_FMA
+}
+
+__global__ __launch_bounds__(kCnnThreads) void cnn_reflectance_regs_kernel(
+    const uint8_t *__restrict__ bgr, float *__restrict__ r_out, uint8_t *__restrict__ r_u8_out,
+    size_t npix, const float *__restrict__ packed, const float *__restrict__ srgb_lut)
+{
+    __shared__ float lut[256];
+    for (int i = threadIdx.x; i < 256; i += kCnnThreads)
+        lut[i] = srgb_lut[i];
+    __syncthreads();
+    const float *wf = packed + 128 + 4 * 1056;
+    const size_t stride = (size_t)gridDim.x * kCnnThreads;
+    const size_t half = (npix + 1) / 2;  // lane handles pixels i and i + half (both stay coalesced)
+    for (size_t i = (size_t)blockIdx.x * kCnnThreads + threadIdx.x; i < half; i += stride) {
+        const size_t idx[kPxPerLane] = {i, i + half};
+        float2v x[3];
+        {
+            const uint8_t *p0 = bgr + idx[0] * 3;
+            const uint8_t *p1 = bgr + (idx[1] < npix ? idx[1] : npix - 1) * 3;
+            x[0] = float2v{lut[p0[2]], lut[p1[2]]};  // blob channel order is RGB
+            x[1] = float2v{lut[p0[1]], lut[p1[1]]};
+            x[2] = float2v{lut[p0[0]], lut[p1[0]]};
+        }
+        float2v A[32], B[32];
+        float z[kPxPerLane] = {0.f, 0.f};
+        // layer 0: 16 channel pairs x 3 inputs, weights {W0[2o][k], W0[2o+1][k]} at packed[6 o + 2 k],
+        // biases at packed[96 + c]; two halves of 8 pairs, each with its own explicit scalar loads
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++) {
+            float16v w0, w1, w2v, bb;
+            asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(w0) : "s"(packed + 48 * hh), "n"(0));
+            asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(w1) : "s"(packed + 48 * hh), "n"(64));
+            asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(w2v) : "s"(packed + 48 * hh), "n"(128));
+            asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(bb) : "s"(packed + 96 + 16 * hh), "n"(0));
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(w0), "+s"(w1), "+s"(w2v), "+s"(bb));
+#pragma unroll
+            for (int o8 = 0; o8 < 8; o8++) {
+                float2v acc0 = float2v{0.f, 0.f}, acc1 = float2v{0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const int e = 6 * o8 + 2 * k;  // element of the 48-float half
+                    const float2v wp = e < 16   ? float2v{w0[e & 15], w0[(e & 15) + 1]}
+                                       : e < 32 ? float2v{w1[e & 15], w1[(e & 15) + 1]}
+                                                : float2v{w2v[e & 15], w2v[(e & 15) + 1]};
+                    RF_PKFMA_P0(acc0, wp, x[k]);
+                    RF_PKFMA_P1(acc1, wp, x[k]);
+                }
+                const int op = 8 * hh + o8;
+                finish_pair(acc0, acc1, bb[2 * o8], bb[2 * o8 + 1], A[2 * op], A[2 * op + 1]);
+            }
+        }
+        fuse32(A, wf, z);
+#pragma unroll 1
+        for (int l = 0; l < 4; l++) {
+            layer32_regs(packed + 128 + l * 1056, A, B);
+            fuse32(B, wf + 32 * (l + 1), z);
+#pragma unroll
+            for (int c = 0; c < 32; c++)
+                A[c] = B[c];
+        }
+#pragma unroll
+        for (int p = 0; p < kPxPerLane; p++) {
+            if (idx[p] >= npix)
+                continue;
+            const float zz = __fadd_rn(z[p], wf[160]);
+            // caffe: 1. / (1. + exp(-x)) with a float exp; expf modelled as round(exp in double)
+            const float e = (float)exp((double)(-zz));
+            const float r = (float)(1.0 / (1.0 + (double)e));
+            if (r_out)
+                r_out[idx[p]] = r;
+            if (r_u8_out)
+                r_u8_out[idx[p]] = (uint8_t)__fmul_rn(r, 255.0f);  // astype(uint8): truncation
+        }
+    }
+}
+#undef RF_PKFMA_P0
+#undef RF_PKFMA_P1
+
 // One packed copy of the weights per (device, stream): a call re-packs the caller's weights on
 // its own stream (18 tiny workgroups; the weights may have changed since the last call), so calls
 // on different streams of one device never share a buffer and calls on one stream are ordered.
@@ -288,8 +473,12 @@ extern "C" int rf_cnn_reflectance_u8(const uint8_t *bgr, float *r_out, uint8_t *
     size_t blocks = ((npix + 1) / 2 + kCnnThreads - 1) / kCnnThreads;
     if (blocks > 256 * 20)
         blocks = 256 * 20;
-    hipLaunchKernelGGL(cnn_reflectance_kernel, dim3((unsigned)blocks), dim3(kCnnThreads), 0, stream,
-                       bgr, r_out, r_u8_out, npix, packed, srgb_lut);
+    if (debug_get(kDbgCnnLdsColumns))  // cross-check: the LDS-column form of round 1
+        hipLaunchKernelGGL(cnn_reflectance_kernel, dim3((unsigned)blocks), dim3(kCnnThreads), 0,
+                           stream, bgr, r_out, r_u8_out, npix, packed, srgb_lut);
+    else
+        hipLaunchKernelGGL(cnn_reflectance_regs_kernel, dim3((unsigned)blocks), dim3(kCnnThreads),
+                           0, stream, bgr, r_out, r_u8_out, npix, packed, srgb_lut);
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;
 }

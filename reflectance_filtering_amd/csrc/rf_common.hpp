@@ -79,6 +79,7 @@ enum DebugOption {
     kDbgJbfTile64Only,     // joint bilateral: 64x64 tiles only (no strip tiles)
     kDbgJbfTune,           // joint bilateral: kernel-variant override (tools/jbf_tune.py), 0 = auto
     kDbgJbfF32Untiled,     // float joint bilateral: one-thread-per-pixel kernel
+    kDbgCnnLdsColumns,     // CNN: activations handed between layers through LDS columns (round-1 form)
     kDbgCount
 };
 int debug_get(int id);

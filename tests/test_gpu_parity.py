@@ -693,3 +693,21 @@ def test_gf_fused_stage2_in_place_chain_and_oracle(env, radius, eps):
     inplace = s.clone()
     rf.ops.guided_filter_u8(g, inplace, radius, eps, iterations=3, out=inplace, workspace=ws)
     assert torch.equal(inplace, got)
+
+
+def test_cnn_register_kernel_equals_lds_column_kernel(env):
+    """The register-resident CNN kernel (default: op_sel-routed inputs, no LDS) and the LDS-column
+    kernel of round 1 run the same FMA chains: identical float outputs and bytes, odd pixel count
+    (the second pixel of the last lane is clamped), custom weights."""
+    from tests import synth
+    rf, co, torch = env
+    imgs = torch.from_numpy(np.stack([synth.scene_u8(77, 131, seed=s) for s in (1, 2, 3)])).cuda()
+    wts = rf.weights.load_weights()
+    for w in (None, (wts * np.float32(1.01)).astype(np.float32)):
+        r, r8 = rf.ops.cnn_reflectance_u8(imgs, weights=w)
+        with rf._ffi.debug_options(cnn_lds_columns=1):
+            r_old, r8_old = rf.ops.cnn_reflectance_u8(imgs, weights=w)
+        assert torch.equal(r, r_old) and torch.equal(r8, r8_old)
+    ref_r, ref_r8 = co.cnn_reflectance(imgs[0].cpu().numpy(), wts)
+    r, r8 = rf.ops.cnn_reflectance_u8(imgs)
+    assert np.abs(r[0].cpu().numpy() - ref_r).max() <= 2e-7
