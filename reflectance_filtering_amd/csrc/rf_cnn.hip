@@ -10,6 +10,9 @@
 // Each dot product is a float32 FMA chain over k ascending starting from 0, then + bias (the
 // bias is a second rank-1 gemm in Caffe).
 //
+// Two kernels with identical values: cnn_reflectance_regs_kernel (default; see the comment block
+// above it) and cnn_reflectance_kernel, the LDS-column form described next (cross-check).
+//
 // Mapping: one lane = two pixels; the 32 activations of a pixel live in VGPRs; every FMA is a
 // v_pk_fma_f32 that advances TWO output channels of one pixel by one k, its weight pair
 // {W[o][k], W[o+1][k]} a wave-uniform 64-bit SGPR operand streamed with s_load_dwordx16 from a
