@@ -199,7 +199,7 @@ __global__ __launch_bounds__(kAThreads) void gf_stage1_kernel(
     constexpr int kACols = stage1_cols(SCN);
     constexpr int kACW = kAThreads * kACols;
     __shared__ uint32_t pfx[NQ][kACW + 1];
-    __shared__ uint32_t wave_tot[NQ][kAWaves];
+    __shared__ uint32_t wave_acc[NQ][kAWaves];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -246,9 +246,26 @@ __global__ __launch_bounds__(kAThreads) void gf_stage1_kernel(
         for (int q = 0; q < NQ; q++)
             pfx[q][0] = 0;
 
+    // wave_acc[q][j] accumulates, over all rows so far, the totals of the waves to the left of
+    // wave j (uint32 wrap-around is exact): a wave adds its total to the entries of the waves to
+    // its right with one LDS atomic per quantity, and every thread gets its row's base as the
+    // difference between the entry now and one row ago - one broadcast read and one subtraction
+    // per quantity instead of kAWaves - 1 reads, selects and adds
+    uint32_t acc_prev[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++)
+        acc_prev[q] = 0;
+    if (tid < kAWaves)
+#pragma unroll
+        for (int q = 0; q < NQ; q++)
+            wave_acc[q][tid] = 0;
+    __syncthreads();
+
     for (int y = ys; y < ye; y++) {
         add_row(y + radius, true);
-        // inclusive prefix over the strip's columns, per quantity
+        // inclusive prefix over the strip's columns, per quantity.  The six DPP steps of the wave
+        // scan run stage by stage across the quantities: back to back on one quantity every step
+        // waits out the VALU-write -> DPP-read hazard (an s_nop per step and quantity)
         uint32_t incl[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
@@ -256,21 +273,35 @@ __global__ __launch_bounds__(kAThreads) void gf_stage1_kernel(
 #pragma unroll
             for (int k = 1; k < kACols; k++)
                 tsum += V[k][q];
-            const uint32_t s = wave_inclusive_scan(tsum);
-            incl[q] = s;
-            if (lane == 63)
-                wave_tot[q][wave] = s;
+            incl[q] = tsum;
+        }
+#define RF_SCAN_STAGE(CTRL, ROWMASK, BOUND)                                                  \
+    _Pragma("unroll") for (int q = 0; q < NQ; q++) incl[q] +=                                \
+        (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl[q], CTRL, ROWMASK, 0xf, BOUND);
+        RF_SCAN_STAGE(0x111, 0xf, true)   // row_shr:1
+        RF_SCAN_STAGE(0x112, 0xf, true)   // row_shr:2
+        RF_SCAN_STAGE(0x114, 0xf, true)   // row_shr:4
+        RF_SCAN_STAGE(0x118, 0xf, true)   // row_shr:8
+        RF_SCAN_STAGE(0x142, 0xa, false)  // row_bcast:15
+        RF_SCAN_STAGE(0x143, 0xc, false)  // row_bcast:31
+#undef RF_SCAN_STAGE
+        {
+            // lanes 0 .. kAWaves-2-wave add the wave total (lane 63's prefix) to the entries of the
+            // waves to the right
+            const int dstw = wave + 1 + lane;
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl[q], 63);
+                if (dstw < kAWaves)
+                    atomicAdd(&wave_acc[q][dstw], tot);
+            }
         }
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
-            // totals of the waves to the left: all read unconditionally (broadcast reads, issued
-            // together) and selected with the wave-uniform index - a loop over `wave` here becomes
-            // a divergent loop with one exposed LDS round trip per iteration and quantity
-            uint32_t base = 0;
-#pragma unroll
-            for (int wv = 0; wv < kAWaves - 1; wv++)
-                base += wv < wave ? wave_tot[q][wv] : 0u;
+            const uint32_t acc = wave_acc[q][wave];
+            const uint32_t base = acc - acc_prev[q];
+            acc_prev[q] = acc;
             uint32_t pk = incl[q] + base;  // inclusive prefix at the thread's last column
 #pragma unroll
             for (int k = kACols - 1; k >= 0; k--) {
