@@ -283,8 +283,15 @@ __global__ __launch_bounds__(kAThreads) void gf_stage1_kernel(
         RF_SCAN_STAGE(0x114, 0xf, true)   // row_shr:4
         RF_SCAN_STAGE(0x118, 0xf, true)   // row_shr:8
         RF_SCAN_STAGE(0x142, 0xa, false)  // row_bcast:15
-        RF_SCAN_STAGE(0x143, 0xc, false)  // row_bcast:31
 #undef RF_SCAN_STAGE
+        // last step (row_bcast:31 into rows 2 and 3) spelled out: hipcc does not fold this one into
+        // the add and emits v_mov 0 / v_mov_dpp / v_add per quantity.  Each statement reads a
+        // register written NQ instructions earlier, so the DPP read hazard is covered.
+        asm volatile("s_nop 1");  // ... whatever hipcc put last before the first statement
+#pragma unroll
+        for (int q = 0; q < NQ; q++)
+            asm volatile("v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+                         : "+v"(incl[q]));
         {
             // lanes 0 .. kAWaves-2-wave add the wave total (lane 63's prefix) to the entries of the
             // waves to the right
