@@ -14,6 +14,8 @@
  *   "jbf_f32_untiled"    float joint bilateral: one-thread-per-pixel kernel; identical values
  *   "cnn_lds_columns"    CNN: activations pass between layers through LDS columns instead of
  *                        registers; identical values
+ *   "gf_seg_rows"        guided filter: rows per stage-1 segment (tools/gf_seg_sweep.py); 0 =
+ *                        chosen by the library; identical bytes
  *   "jbf_stage_only"     joint bilateral: stage the tile and return WITHOUT WRITING dst
  *                        (tools/jbf_tune.py --stage-only, timing only)
  */

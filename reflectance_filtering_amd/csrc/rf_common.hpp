@@ -80,6 +80,7 @@ enum DebugOption {
     kDbgJbfTune,           // joint bilateral: kernel-variant override (tools/jbf_tune.py), 0 = auto
     kDbgJbfF32Untiled,     // float joint bilateral: one-thread-per-pixel kernel
     kDbgCnnLdsColumns,     // CNN: activations handed between layers through LDS columns (round-1 form)
+    kDbgGfSegRows,         // guided filter: rows per stage-1 segment (0 = chosen by the library)
     kDbgCount
 };
 int debug_get(int id);

@@ -1044,11 +1044,16 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
                                                             : (size_t)m * np * npx));
         const uint8_t *g0 = guide + (size_t)i0 * npx * 3;
         uint8_t *d0 = dst + (size_t)i0 * npx * src_cn;
-        // row segments: enough workgroups to fill 256 CUs, but segments no shorter than 2r+1
+        // row segments: enough workgroups to fill 256 CUs, but segments no shorter than 2r+1.
+        // (tools/gf_seg_sweep.py: a pass is flat within 3 % between 34 and 135 rows per segment at
+        // 4K - the 2r warm-up rows of a segment are cheap - and slower above; a model that picks
+        // the segment count by whole rounds of resident workgroups was no better.)
         int seg_rows = h;
         while ((long long)strips * ceil_div(h, seg_rows) * m < 1024 && seg_rows > 2 * (2 * radius + 1) &&
                seg_rows > 32)
             seg_rows = (seg_rows + 1) / 2;
+        if (debug_get(kDbgGfSegRows) > 0)
+            seg_rows = std::min(h, debug_get(kDbgGfSegRows));
         const int segs = ceil_div(h, seg_rows);
         for (int it = 0; it < iterations; it++) {
             const uint8_t *s0 = (it == 0 ? src : (const uint8_t *)dst) + (size_t)i0 * npx * src_cn;

@@ -688,6 +688,10 @@ def test_gf_fused_stage2_in_place_chain_and_oracle(env, radius, eps):
     assert np.array_equal(got.cpu().numpy(), np.stack(want))
     with rf._ffi.debug_options(gf_two_kernel=1):
         assert torch.equal(rf.ops.guided_filter_u8(g, s, radius, eps, iterations=3), got)
+    # stage 1 cut into row segments of any height (each restarts its exact integer window sums)
+    for seg_rows in (1, 17, 64, 1000):
+        with rf._ffi.debug_options(gf_seg_rows=seg_rows):
+            assert torch.equal(rf.ops.guided_filter_u8(g, s, radius, eps, iterations=3), got)
     one = rf._ffi.load_library().rf_gf_workspace_bytes(1, h, w, 3, 3, radius)
     ws = torch.empty(one, dtype=torch.uint8, device="cuda")
     inplace = s.clone()
