@@ -37,11 +37,15 @@ namespace {
 // ------------------------------------------------------------------------------------------
 // stage 1 + per-pixel algebra
 // ------------------------------------------------------------------------------------------
-constexpr int kAThreads = 256;
-constexpr int kAWaves = kAThreads / 64;
-// columns per thread (strip width incl. halo = 256 x that): 3 for one computed src channel
-// (13 quantities: 40 KB of prefix sums, 4 workgroups per CU; 768-column strips waste less on the
-// 2r-column halo and on the last strip of a 3840-wide image), 2 for three (21 quantities)
+// Threads per workgroup and columns per thread (strip width incl. halo = threads x columns) by
+// the number of src channels computed.  One channel (13 quantities): 256 x 3 - 40 KB of prefix
+// sums, 4 workgroups = 16 waves per CU, 768-column strips (2r of them halo).  Three channels
+// (21 quantities): 256 x 2 - 43 KB, 3 workgroups = 12 waves per CU.  Measured alternatives for
+// three channels (8 x 4K pass, best rows per segment each): 320 x 2 (15 waves per CU, seven
+// strips cover 3840 columns exactly, but five waves per workgroup load the four SIMDs unevenly
+// between barriers) 5.04 ms against 4.95; 512 x 1 at 80 registers (24 waves per CU, a fifth
+// more scan work per pixel) 5.56 ms.
+constexpr int stage1_threads(int) { return 256; }
 constexpr int stage1_cols(int scn) { return scn == 1 ? 3 : 2; }
 
 template <int SCN>
@@ -188,7 +192,7 @@ __device__ inline bool wrong_variant(const int *__restrict__ colour, int img)
 // SCN = src channels computed, SPX = src bytes per pixel (SCN, or 3 with SCN = 1 for a grey
 // 3-channel image whose first channel stands for all three).
 template <int SCN, int SPX>
-__global__ __launch_bounds__(kAThreads) void gf_stage1_kernel(
+__global__ __launch_bounds__(stage1_threads(SCN)) void gf_stage1_kernel(
     const uint8_t *__restrict__ guide, const uint8_t *__restrict__ src, float *__restrict__ ab,
     int h, int w, int radius, float eps_f, int eps_small, int seg_rows,
     const int *__restrict__ colour)
@@ -196,6 +200,7 @@ __global__ __launch_bounds__(kAThreads) void gf_stage1_kernel(
     if (wrong_variant<SCN>(colour, blockIdx.z))
         return;
     constexpr int NQ = Quant<SCN>::NQ;
+    constexpr int kAThreads = stage1_threads(SCN), kAWaves = kAThreads / 64;
     constexpr int kACols = stage1_cols(SCN);
     constexpr int kACW = kAThreads * kACols;
     __shared__ uint32_t pfx[NQ][kACW + 1];
@@ -1017,9 +1022,9 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
         chunk = 16383;
     const float eps_f = (float)eps;
     const int eps_small = eps < 1e-2;
-    // stage-1 strips: 256 threads x stage1_cols columns, 2r of them halo
-    const int strips3 = ceil_div(w, kAThreads * stage1_cols(3) - 2 * radius);
-    const int strips1 = ceil_div(w, kAThreads * stage1_cols(1) - 2 * radius);
+    // stage-1 strips: stage1_threads x stage1_cols columns, 2r of them halo
+    const int strips3 = ceil_div(w, stage1_threads(3) * stage1_cols(3) - 2 * radius);
+    const int strips1 = ceil_div(w, stage1_threads(1) * stage1_cols(1) - 2 * radius);
     const int strips = src_cn == 3 ? strips3 : strips1;
 
     // 3-channel sources: find the images whose channels are identical (see the file header)
@@ -1059,12 +1064,12 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
             const uint8_t *s0 = (it == 0 ? src : (const uint8_t *)dst) + (size_t)i0 * npx * src_cn;
             const dim3 ga3(strips3, segs, m), ga1(strips1, segs, m);
             if (src_cn == 3) {
-                hipLaunchKernelGGL((gf_stage1_kernel<3, 3>), ga3, dim3(kAThreads), 0, stream, g0, s0,
+                hipLaunchKernelGGL((gf_stage1_kernel<3, 3>), ga3, dim3(stage1_threads(3)), 0, stream, g0, s0,
                                    ab, h, w, radius, eps_f, eps_small, seg_rows, colour);
-                hipLaunchKernelGGL((gf_stage1_kernel<1, 3>), ga1, dim3(kAThreads), 0, stream, g0, s0,
+                hipLaunchKernelGGL((gf_stage1_kernel<1, 3>), ga1, dim3(stage1_threads(1)), 0, stream, g0, s0,
                                    ab, h, w, radius, eps_f, eps_small, seg_rows, colour);
             } else {
-                hipLaunchKernelGGL((gf_stage1_kernel<1, 1>), ga1, dim3(kAThreads), 0, stream, g0, s0,
+                hipLaunchKernelGGL((gf_stage1_kernel<1, 1>), ga1, dim3(stage1_threads(1)), 0, stream, g0, s0,
                                    ab, h, w, radius, eps_f, eps_small, seg_rows, colour);
             }
             const int row_blocks = ceil_div(h, kBRows);
