@@ -37,7 +37,8 @@ extern "C" int rf_debug_option(const char *name, int value)
     static const char *const names[rf::kDbgCount] = {"gf_two_kernel",     "jbf_stage_only",
                                                       "jbf_compiler_loop", "jbf_tile64_only",
                                                       "jbf_tune",          "jbf_f32_untiled",
-                                                      "cnn_lds_columns",   "gf_seg_rows"};
+                                                      "cnn_lds_columns",   "gf_seg_rows",
+                                                      "gf_two_streams"};
     if (name)
         for (int i = 0; i < rf::kDbgCount; i++)
             if (std::strcmp(name, names[i]) == 0)

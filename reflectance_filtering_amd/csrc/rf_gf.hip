@@ -30,6 +30,7 @@
 #include "rf_common.hpp"
 
 #include <algorithm>
+#include <mutex>
 
 namespace rf {
 namespace {
@@ -951,6 +952,21 @@ int gf_f32_chunk(const float *guide, const float *src, float *dst, int m, int h,
 
 }  // namespace
 
+// The library's side stream of the current device (created on first use, lives until exit).
+hipStream_t gf_side_stream()
+{
+    static std::mutex mu;
+    static hipStream_t streams[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+        return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (streams[dev] == nullptr &&
+        hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking) != hipSuccess)
+        streams[dev] = nullptr;
+    return streams[dev];
+}
+
 // per-image "has colour" flags at the head of the workspace
 size_t gf_header_bytes(int n) { return (((size_t)n * sizeof(int)) + 255) & ~(size_t)255; }
 
@@ -1040,11 +1056,11 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
         }
     }
 
-    for (int i0 = 0; i0 < n; i0 += chunk) {
-        const int m = std::min(chunk, n - i0);
+    // One part = m images starting at i0, their scratch at ws, every launch on st.
+    auto run_part = [&](int i0, int m, int m_fill, char *ws, hipStream_t st) {
         const int *colour = colour_all ? colour_all + i0 : nullptr;
         // two-kernel form: [row sums (double)][alpha/beta]; fused form: [states (double)][alpha/beta]
-        double *rows = reinterpret_cast<double *>(static_cast<char *>(workspace) + header);
+        double *rows = reinterpret_cast<double *>(ws);
         float *ab = reinterpret_cast<float *>(rows + (fused ? (size_t)m * np * nb * h
                                                             : (size_t)m * np * npx));
         const uint8_t *g0 = guide + (size_t)i0 * npx * 3;
@@ -1053,9 +1069,10 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
         // (tools/gf_seg_sweep.py: a pass is flat within 3 % between 34 and 135 rows per segment at
         // 4K - the 2r warm-up rows of a segment are cheap - and slower above; a model that picks
         // the segment count by whole rounds of resident workgroups was no better.)
+        // (m_fill: the images in flight on the device, i.e. both halves of a chunk)
         int seg_rows = h;
-        while ((long long)strips * ceil_div(h, seg_rows) * m < 1024 && seg_rows > 2 * (2 * radius + 1) &&
-               seg_rows > 32)
+        while ((long long)strips * ceil_div(h, seg_rows) * m_fill < 1024 &&
+               seg_rows > 2 * (2 * radius + 1) && seg_rows > 32)
             seg_rows = (seg_rows + 1) / 2;
         if (debug_get(kDbgGfSegRows) > 0)
             seg_rows = std::min(h, debug_get(kDbgGfSegRows));
@@ -1064,34 +1081,34 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
             const uint8_t *s0 = (it == 0 ? src : (const uint8_t *)dst) + (size_t)i0 * npx * src_cn;
             const dim3 ga3(strips3, segs, m), ga1(strips1, segs, m);
             if (src_cn == 3) {
-                hipLaunchKernelGGL((gf_stage1_kernel<3, 3>), ga3, dim3(stage1_threads(3)), 0, stream, g0, s0,
+                hipLaunchKernelGGL((gf_stage1_kernel<3, 3>), ga3, dim3(stage1_threads(3)), 0, st, g0, s0,
                                    ab, h, w, radius, eps_f, eps_small, seg_rows, colour);
-                hipLaunchKernelGGL((gf_stage1_kernel<1, 3>), ga1, dim3(stage1_threads(1)), 0, stream, g0, s0,
+                hipLaunchKernelGGL((gf_stage1_kernel<1, 3>), ga1, dim3(stage1_threads(1)), 0, st, g0, s0,
                                    ab, h, w, radius, eps_f, eps_small, seg_rows, colour);
             } else {
-                hipLaunchKernelGGL((gf_stage1_kernel<1, 1>), ga1, dim3(stage1_threads(1)), 0, stream, g0, s0,
+                hipLaunchKernelGGL((gf_stage1_kernel<1, 1>), ga1, dim3(stage1_threads(1)), 0, st, g0, s0,
                                    ab, h, w, radius, eps_f, eps_small, seg_rows, colour);
             }
             const int row_blocks = ceil_div(h, kBRows);
             if (fused) {
                 if (radius == 45)
                     hipLaunchKernelGGL((gf_rowstate_kernel<45>), dim3((unsigned)(m * np * row_blocks)),
-                                       dim3(64), 0, stream, ab, rows, h, w, row_blocks, np, colour, np, nb);
+                                       dim3(64), 0, st, ab, rows, h, w, row_blocks, np, colour, np, nb);
                 else
                     hipLaunchKernelGGL((gf_rowstate_kernel<52>), dim3((unsigned)(m * np * row_blocks)),
-                                       dim3(64), 0, stream, ab, rows, h, w, row_blocks, np, colour, np, nb);
+                                       dim3(64), 0, st, ab, rows, h, w, row_blocks, np, colour, np, nb);
                 const int it3 = m * 3 * nb, it1 = m * nb;
                 const dim3 g3(8 * (unsigned)ceil_div(it3, 8)), g1(8 * (unsigned)ceil_div(it1, 8));
 #define RF_GF_WALK(R, TT)                                                                             \
     do {                                                                                           \
         if (src_cn == 3) {                                                                         \
-            hipLaunchKernelGGL((gf_colwalk_kernel<R, TT, 3, 3>), g3, dim3(64), 0, stream, ab, rows, g0, \
-                               d0, h, w, nb, it3, colour);                                         \
-            hipLaunchKernelGGL((gf_colwalk_kernel<R, TT, 1, 3>), g1, dim3(64), 0, stream, ab, rows, g0, \
-                               d0, h, w, nb, it1, colour);                                         \
+            hipLaunchKernelGGL((gf_colwalk_kernel<R, TT, 3, 3>), g3, dim3(64), 0, st, ab, rows, g0, d0, \
+                               h, w, nb, it3, colour);                                             \
+            hipLaunchKernelGGL((gf_colwalk_kernel<R, TT, 1, 3>), g1, dim3(64), 0, st, ab, rows, g0, d0, \
+                               h, w, nb, it1, colour);                                             \
         } else {                                                                                   \
-            hipLaunchKernelGGL((gf_colwalk_kernel<R, TT, 1, 1>), g1, dim3(64), 0, stream, ab, rows, g0, \
-                               d0, h, w, nb, it1, colour);                                         \
+            hipLaunchKernelGGL((gf_colwalk_kernel<R, TT, 1, 1>), g1, dim3(64), 0, st, ab, rows, g0, d0, \
+                               h, w, nb, it1, colour);                                             \
         }                                                                                          \
     } while (0)
                 if (radius == 45)
@@ -1102,18 +1119,50 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
                 continue;
             }
             hipLaunchKernelGGL(gf_rowsum_kernel, dim3((unsigned)(m * np * row_blocks)), dim3(64), 0,
-                               stream, ab, rows, h, w, radius, row_blocks, np, colour, np);
+                               st, ab, rows, h, w, radius, row_blocks, np, colour, np);
             dim3 gc(ceil_div(w, 64), 1, m);
             if (src_cn == 3) {
-                hipLaunchKernelGGL((gf_colsum_apply_kernel<3, 3>), gc, dim3(64, 12), 0, stream, rows,
+                hipLaunchKernelGGL((gf_colsum_apply_kernel<3, 3>), gc, dim3(64, 12), 0, st, rows,
                                    g0, d0, h, w, radius, colour);
-                hipLaunchKernelGGL((gf_colsum_apply_kernel<1, 3>), gc, dim3(64, 4), 0, stream, rows,
+                hipLaunchKernelGGL((gf_colsum_apply_kernel<1, 3>), gc, dim3(64, 4), 0, st, rows,
                                    g0, d0, h, w, radius, colour);
             } else {
-                hipLaunchKernelGGL((gf_colsum_apply_kernel<1, 1>), gc, dim3(64, 4), 0, stream, rows,
+                hipLaunchKernelGGL((gf_colsum_apply_kernel<1, 1>), gc, dim3(64, 4), 0, st, rows,
                                    g0, d0, h, w, radius, colour);
             }
         }
+    };
+
+    // Optional (debug option "gf_two_streams"): a chunk of two or more images runs as two halves on
+    // two streams - the caller's and a side stream of the library, forked and joined with events,
+    // so the call still looks stream-ordered to the caller and can be captured into a graph.
+    // Measured at 8 x 4K: colour sources 8.7 % faster (stage 1 leaves 30 KB of LDS and a quarter
+    // of the registers of a CU free, which the other half's column-walk waves use), grey sources
+    // 2-5 % slower (their stage 1 fills the LDS; only the extra launches and tails remain).  The
+    // host cannot know which of the two a 3-channel buffer holds without a round trip, and the
+    // reference's guided filter runs on grey maps, so the default is one stream.
+    char *ws0 = static_cast<char *>(workspace) + header;
+    hipStream_t side = nullptr;
+    if (fused && chunk >= 2 && debug_get(kDbgGfTwoStreams))
+        side = gf_side_stream();
+    for (int i0 = 0; i0 < n; i0 += chunk) {
+        const int m = std::min(chunk, n - i0);
+        if (side == nullptr || m < 2) {
+            run_part(i0, m, m, ws0, stream);
+            continue;
+        }
+        const int ma = (m + 1) / 2;
+        hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+        RF_HIP_CHECK(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
+        RF_HIP_CHECK(hipEventCreateWithFlags(&join_ev, hipEventDisableTiming));
+        RF_HIP_CHECK(hipEventRecord(fork_ev, stream));
+        RF_HIP_CHECK(hipStreamWaitEvent(side, fork_ev, 0));
+        run_part(i0, ma, m, ws0, stream);
+        run_part(i0 + ma, m - ma, m, ws0 + (size_t)ma * per_img_used, side);
+        RF_HIP_CHECK(hipEventRecord(join_ev, side));
+        RF_HIP_CHECK(hipStreamWaitEvent(stream, join_ev, 0));
+        RF_HIP_CHECK(hipEventDestroy(fork_ev));
+        RF_HIP_CHECK(hipEventDestroy(join_ev));
     }
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;

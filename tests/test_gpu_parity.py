@@ -634,6 +634,26 @@ def test_captured_call_replays_the_chain(env):
         assert torch.equal(a, want_gf) and torch.equal(b, want_bf), seed
 
 
+def test_captured_call_with_forked_guided_filter(env):
+    """With the debug option gf_two_streams the guided filter forks a side stream inside the call
+    and joins it before returning: the call can still be captured into a HIP graph, and the replay
+    gives the eager one-stream bytes (radius 45: fused stage 2, two images = two halves)."""
+    from tests import synth
+    rf, co, torch = env
+    h, w = 120, 150
+    g = torch.from_numpy(np.stack([synth.flat_guide_u8(h, w, seed=k, cells=12) for k in (1, 2)])).cuda()
+    s = torch.from_numpy(np.stack([synth.scene_u8(h, w, seed=k) for k in (3, 4)])).cuda()
+    out = torch.empty_like(s)
+    ws = rf.ops.gf_workspace(2, h, w, 3, 45, s.device, torch)
+    want = rf.ops.guided_filter_u8(g, s, 45, 3.0, iterations=2)
+    with rf._ffi.debug_options(gf_two_streams=1):
+        cap = rf.ops.CapturedCall(lambda: rf.ops.guided_filter_u8(g, s, 45, 3.0, iterations=2,
+                                                                   out=out, workspace=ws))
+        got = cap.replay()
+        torch.cuda.synchronize()
+    assert torch.equal(got, want)
+
+
 def test_two_streams_do_not_share_scratch(env):
     """Guided-filter workspaces are cached per (device, stream) and the CNN's packed weights live
     in a per-(device, stream) buffer: calls in flight on two streams give the bytes of the
@@ -692,6 +712,9 @@ def test_gf_fused_stage2_in_place_chain_and_oracle(env, radius, eps):
     for seg_rows in (1, 17, 64, 1000):
         with rf._ffi.debug_options(gf_seg_rows=seg_rows):
             assert torch.equal(rf.ops.guided_filter_u8(g, s, radius, eps, iterations=3), got)
+    # the two images on two streams (forked and joined inside the call)
+    with rf._ffi.debug_options(gf_two_streams=1):
+        assert torch.equal(rf.ops.guided_filter_u8(g, s, radius, eps, iterations=3), got)
     one = rf._ffi.load_library().rf_gf_workspace_bytes(1, h, w, 3, 3, radius)
     ws = torch.empty(one, dtype=torch.uint8, device="cuda")
     inplace = s.clone()
