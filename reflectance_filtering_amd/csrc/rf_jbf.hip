@@ -1649,10 +1649,14 @@ __global__ __launch_bounds__(256) void jbf_f32_kernel(
 // disk carry weight 0 (adds +0 to the sums: the tap order per output is OpenCV's), and tiles
 // away from the image border skip borderInterpolate.  Same float operations per tap as
 // jbf_f32_kernel, so the values are identical.
-constexpr int kF32TileW = 64, kF32TileH = 16;
+// Tile height by texel size (measured at 1080p, radius 33: 6-float texels 7.4 / 8.1 / 9.4 ms with
+// 16 / 32 / 64 rows - the texel loads thrash the vector cache with more waves per CU - 4-float
+// texels 6.3 / 5.1 / 5.9 ms, 2-float texels 4.4 / 3.9 / 3.9 ms).
+constexpr int kF32TileW = 64;
+constexpr int f32_tile_h(int jcn, int scn) { return jcn + scn >= 6 ? 16 : 32; }
 
 template <int JCN, int SCN>
-__global__ __launch_bounds__(256) void jbf_f32_quad_kernel(
+__global__ __launch_bounds__(16 * f32_tile_h(JCN, SCN)) void jbf_f32_quad_kernel(
     const float *__restrict__ joint, const float *__restrict__ src, float *__restrict__ dst, int h,
     int w, int border, const float *__restrict__ luts, int lut_stride,
     const float *__restrict__ scales, const float *__restrict__ swsym, int sw_len, int r4,
@@ -1661,12 +1665,13 @@ __global__ __launch_bounds__(256) void jbf_f32_quad_kernel(
     extern __shared__ __align__(16) float f32_smem[];
     float *lut_s = f32_smem;                       // [lut_stride]
     float *sw_s = f32_smem + ((lut_stride + 3) & ~3);  // [(radius + 1) * sw_len]
+    constexpr int kF32TileH = f32_tile_h(JCN, SCN), kF32Threads = 16 * kF32TileH;
     const int tid = threadIdx.x;
     {
         const float *lut = luts + (size_t)blockIdx.z * lut_stride;
-        for (int i = tid; i < lut_stride; i += 256)
+        for (int i = tid; i < lut_stride; i += kF32Threads)
             lut_s[i] = lut[i];
-        for (int i = tid; i < (radius + 1) * sw_len; i += 256)
+        for (int i = tid; i < (radius + 1) * sw_len; i += kF32Threads)
             sw_s[i] = swsym[i];
     }
     __syncthreads();
@@ -2002,13 +2007,14 @@ extern "C" int rf_jbf_f32(const float *joint, const float *src, float *dst, int 
     const size_t quad_lds = (size_t)(((bins + 2 + 3) & ~3) + (radius + 1) * t.sw_len) * sizeof(float);
     const bool quad = quad_lds <= 64 * 1024 && !debug_get(kDbgJbfF32Untiled);
     dim3 grid(ceil_div(w, 64), ceil_div(h, 4), n);
-    dim3 gridq(ceil_div(w, kF32TileW), ceil_div(h, kF32TileH), n);
 #define RF_F32(J_, S_)                                                                         \
     do {                                                                                       \
         if (quad)                                                                              \
-            hipLaunchKernelGGL((jbf_f32_quad_kernel<J_, S_>), gridq, dim3(256), quad_lds, stream, \
-                               joint, src, dst, h, w, border, d_luts, bins + 2, d_scale,       \
-                               t.d_swsym, t.sw_len, t.r4, radius, t.d_hw);                     \
+            hipLaunchKernelGGL((jbf_f32_quad_kernel<J_, S_>),                                  \
+                               dim3(ceil_div(w, kF32TileW), ceil_div(h, f32_tile_h(J_, S_)), n), \
+                               dim3(16 * f32_tile_h(J_, S_)), quad_lds, stream, joint, src, dst, \
+                               h, w, border, d_luts, bins + 2, d_scale, t.d_swsym, t.sw_len,   \
+                               t.r4, radius, t.d_hw);                                          \
         else                                                                                   \
             hipLaunchKernelGGL((jbf_f32_kernel<J_, S_>), grid, dim3(256), 0, stream, joint, src, \
                                dst, h, w, border, d_luts, bins + 2, d_scale, t.d_di, t.d_dj,   \
