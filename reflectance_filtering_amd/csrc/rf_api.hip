@@ -34,11 +34,12 @@ int debug_get(int id) { return g_debug[id].load(std::memory_order_relaxed); }
 
 extern "C" int rf_debug_option(const char *name, int value)
 {
-    static const char *const names[rf::kDbgCount] = {"gf_two_kernel",     "jbf_stage_only",
+    static const char *const names[] = {"gf_two_kernel",     "jbf_stage_only",
                                                       "jbf_compiler_loop", "jbf_tile64_only",
                                                       "jbf_tune",          "jbf_f32_untiled",
                                                       "cnn_lds_columns",   "gf_seg_rows",
                                                       "gf_two_streams"};
+    static_assert(sizeof(names) / sizeof(names[0]) == rf::kDbgCount, "one name per DebugOption");
     if (name)
         for (int i = 0; i < rf::kDbgCount; i++)
             if (std::strcmp(name, names[i]) == 0)

@@ -1152,17 +1152,24 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
             continue;
         }
         const int ma = (m + 1) / 2;
-        hipEvent_t fork_ev = nullptr, join_ev = nullptr;
-        RF_HIP_CHECK(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
-        RF_HIP_CHECK(hipEventCreateWithFlags(&join_ev, hipEventDisableTiming));
-        RF_HIP_CHECK(hipEventRecord(fork_ev, stream));
-        RF_HIP_CHECK(hipStreamWaitEvent(side, fork_ev, 0));
+        struct Events {  // destroyed on every path out (a pending event is released on completion)
+            hipEvent_t fork = nullptr, join = nullptr;
+            ~Events()
+            {
+                if (fork)
+                    (void)hipEventDestroy(fork);
+                if (join)
+                    (void)hipEventDestroy(join);
+            }
+        } ev;
+        RF_HIP_CHECK(hipEventCreateWithFlags(&ev.fork, hipEventDisableTiming));
+        RF_HIP_CHECK(hipEventCreateWithFlags(&ev.join, hipEventDisableTiming));
+        RF_HIP_CHECK(hipEventRecord(ev.fork, stream));
+        RF_HIP_CHECK(hipStreamWaitEvent(side, ev.fork, 0));
         run_part(i0, ma, m, ws0, stream);
         run_part(i0 + ma, m - ma, m, ws0 + (size_t)ma * per_img_used, side);
-        RF_HIP_CHECK(hipEventRecord(join_ev, side));
-        RF_HIP_CHECK(hipStreamWaitEvent(stream, join_ev, 0));
-        RF_HIP_CHECK(hipEventDestroy(fork_ev));
-        RF_HIP_CHECK(hipEventDestroy(join_ev));
+        RF_HIP_CHECK(hipEventRecord(ev.join, side));
+        RF_HIP_CHECK(hipStreamWaitEvent(stream, ev.join, 0));
     }
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;
