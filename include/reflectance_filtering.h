@@ -81,6 +81,9 @@ int rf_jbf_u8(const uint8_t *joint, const uint8_t *src, uint8_t *dst, int n, int
  *   result of one pass being the src of the next (the reference's "3x GF" chain of CLI runs).
  *   workspace: device scratch of at least rf_gf_workspace_bytes(1, ...) bytes; larger
  *   workspaces let more images of the batch be in flight at once.
+ *   stream: all work is ordered after what `stream` holds at the call and before what is
+ *   enqueued on it afterwards; inside, half of a batch may run on a side stream of the library
+ *   that is forked from and joined back into `stream` with events (graph capture keeps working).
  */
 size_t rf_gf_workspace_bytes(int n, int h, int w, int guide_cn, int src_cn, int radius);
 int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, int n, int h, int w,

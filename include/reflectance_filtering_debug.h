@@ -16,9 +16,9 @@
  *                        registers; identical values
  *   "gf_seg_rows"        guided filter: rows per stage-1 segment (tools/gf_seg_sweep.py); 0 =
  *                        chosen by the library; identical bytes
- *   "gf_two_streams"     guided filter: the two halves of a batch run on the caller's stream and
- *                        on a side stream of the library (forked / joined with events); +9 % on
- *                        colour sources, -3 % on grey ones at 8 x 4K; identical bytes
+ *   "gf_one_stream"      guided filter: the whole batch on the caller's stream (the default runs
+ *                        the two halves of a batch on the caller's stream and on a side stream of
+ *                        the library, forked / joined with events inside the call); identical bytes
  *   "jbf_stage_only"     joint bilateral: stage the tile and return WITHOUT WRITING dst
  *                        (tools/jbf_tune.py --stage-only, timing only)
  */

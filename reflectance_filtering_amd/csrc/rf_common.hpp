@@ -81,7 +81,7 @@ enum DebugOption {
     kDbgJbfF32Untiled,     // float joint bilateral: one-thread-per-pixel kernel
     kDbgCnnLdsColumns,     // CNN: activations handed between layers through LDS columns (round-1 form)
     kDbgGfSegRows,         // guided filter: rows per stage-1 segment (0 = chosen by the library)
-    kDbgGfTwoStreams,      // guided filter: halves of a chunk on the caller's stream and a side stream
+    kDbgGfOneStream,       // guided filter: the whole chunk on the caller's stream (no side stream)
     kDbgCount
 };
 int debug_get(int id);

@@ -189,7 +189,7 @@ __device__ inline bool wrong_variant(const int *__restrict__ colour, int img)
     return colour != nullptr && (colour[img] != 0) != (SCN == 3);
 }
 
-// grid: (strips, row segments, images).  ab: [img][SPX*4][h][w] float (g<3 alpha, g=3 beta).
+// grid: (strips, row segments, images).  ab: [img][SPX][h][w][4] float (g<3 alpha, g=3 beta).
 // SCN = src channels computed, SPX = src bytes per pixel (SCN, or 3 with SCN = 1 for a grey
 // 3-channel image whose first channel stands for all three).
 template <int SCN, int SPX>
@@ -336,9 +336,12 @@ __global__ __launch_bounds__(stage1_threads(SCN)) void gf_stage1_kernel(
             const size_t pix = (size_t)y * w + x;
             float ab_px[4 * SCN];
             gf_pixel_algebra<SCN>(m, eps_f, eps_small, ab_px);
+            // the four planes of a src channel (alpha_0..2, beta) interleaved per pixel: one
+            // 16-byte store, and stage 2 reads 256-byte runs per image row instead of 64-byte ones
 #pragma unroll
-            for (int e = 0; e < 4 * SCN; e++)
-                abimg[(size_t)e * npx + pix] = ab_px[e];
+            for (int sc = 0; sc < SCN; sc++)
+                *reinterpret_cast<float4 *>(abimg + ((size_t)sc * npx + pix) * 4) =
+                    make_float4(ab_px[4 * sc], ab_px[4 * sc + 1], ab_px[4 * sc + 2], ab_px[4 * sc + 3]);
         }
         add_row(y - radius, false);
     }
@@ -352,11 +355,14 @@ __global__ __launch_bounds__(stage1_threads(SCN)) void gf_stage1_kernel(
 constexpr int kBRows = 64;
 constexpr int kBChunk = 32;
 
-// planes: [img][src_np][h][w] of which the first np per image are summed; rowsums: [img][np][h][w]
+// planes: [img][src_np][h][w] (il = 1) or [img][src_np / 4][h][w][4] (il = 4: groups of four
+// planes interleaved per pixel, the layout stage 1 writes), of which the first np per image are
+// summed; rowsums: [img][np][h][w]
 __global__ __launch_bounds__(64) void gf_rowsum_kernel(const float *__restrict__ planes,
                                                        double *__restrict__ rowsums, int h, int w,
                                                        int radius, int row_blocks, int np,
-                                                       const int *__restrict__ colour, int src_np)
+                                                       const int *__restrict__ colour, int src_np,
+                                                       int il)
 {
     {
         // grey 3-channel images only carry the 4 planes of their first channel
@@ -371,7 +377,8 @@ __global__ __launch_bounds__(64) void gf_rowsum_kernel(const float *__restrict__
     const int lane = threadIdx.x;
     const int plane = blockIdx.x / row_blocks;  // plane index across the whole chunk of images
     const int row0 = (blockIdx.x - plane * row_blocks) * kBRows;
-    const float *S = planes + ((size_t)(plane / np) * src_np + plane % np) * h * w;
+    const int q = plane % np;  // plane of the image
+    const float *S = planes + ((size_t)(plane / np) * src_np + q / il * il) * h * w + q % il;
     double *D = rowsums + (size_t)plane * h * w;
     const int ks = 2 * radius + 1;
     const int sub = lane >> 5, col = lane & 31;  // loader role: 2 rows x 32 columns per instruction
@@ -383,7 +390,7 @@ __global__ __launch_bounds__(64) void gf_rowsum_kernel(const float *__restrict__
         const int sx = border_interpolate(min(xi, ks - 1) - radius, w, RF_BORDER_REFLECT);
         for (int rr = 0; rr < kBRows; rr += 2) {
             const int row = min(row0 + rr + sub, h - 1);
-            t_in[rr + sub][col] = S[(size_t)row * w + sx];
+            t_in[rr + sub][col] = S[((size_t)row * w + sx) * il];
         }
         __syncthreads();
         const int cnt = min(kBChunk, ks - i0);
@@ -399,8 +406,8 @@ __global__ __launch_bounds__(64) void gf_rowsum_kernel(const float *__restrict__
         const int sl = border_interpolate(min(o, w - 1) - 1 - radius, w, RF_BORDER_REFLECT);
         for (int rr = 0; rr < kBRows; rr += 2) {
             const int row = min(row0 + rr + sub, h - 1);
-            t_in[rr + sub][col] = S[(size_t)row * w + se];
-            t_out_lo[rr + sub][col] = S[(size_t)row * w + sl];
+            t_in[rr + sub][col] = S[((size_t)row * w + se) * il];
+            t_out_lo[rr + sub][col] = S[((size_t)row * w + sl) * il];
         }
         __syncthreads();
         const int cnt = min(kBChunk, w - o0);
@@ -519,64 +526,123 @@ __global__ __launch_bounds__(64 * 4 * SCN) void gf_colsum_apply_kernel(
 // ------------------------------------------------------------------------------------------
 constexpr int kSB = 16;      // columns per state block and per column-walk wave
 
-// planes: [img][src_np][h][w]; states: [img * np + plane][nb][h], nb = ceil(w / 16);
-// states[..][b][row] = RowSum at column 16 b.  grid: (planes of the chunk) x (64-row blocks).
-// One wave per workgroup, lane = row, walking the border-extended row ext[i] = S[bi(i - r)] from
-// its left end.  The value leaving the window, ext[i - ks], is the value that entered ks steps
-// earlier in the same lane: it is kept in a register FIFO of F >= ks floats, F a multiple of 16
-// (slot = step mod F, static because the loop body is one period of F steps, fully unrolled) -
-// no second read and only 4 KB of LDS (the transposition of one chunk of 16 columns), so a dozen
-// waves share a CU and hide each other's memory latency.  The stream is prefixed with PAD dummy
-// steps so that every chunk of 16 steps is a 64-byte-aligned run of 16 source columns.
+// planes: [img][src_np / 4][h][w][4] (the four planes of a src channel interleaved per pixel);
+// states: [img * np + plane][nb][h], nb = ceil(w / 16); states[..][b][row] = RowSum at column 16 b.
+// grid: (plane groups of the chunk) x (64-row blocks); one workgroup = 4 waves = the 4 planes of
+// a group, lane = row, walking the border-extended row ext[i] = S[bi(i - r)] from its left end.
+// The workgroup fetches a chunk of 16 columns x 64 rows as float4 pixels (256 contiguous bytes per
+// image row and load) and hands each wave its plane through LDS (20 KB).  The value leaving the
+// window, ext[i - ks], is the value that entered ks steps earlier in the same lane: it is kept in
+// a register FIFO of F >= ks floats, F a multiple of 16 (slot = step mod F, static because the
+// loop body is one period of F steps, fully unrolled) - no second read.  The stream is prefixed
+// with PAD dummy steps so that every chunk of 16 steps is an aligned run of 16 source columns.
+// A workgroup walks its rows alone from end to end (252 chunks at 4K), so the time of the kernel
+// is the time of a chunk: two chunks of loads are in flight, and a full chunk reads its 16
+// operands with four 16-byte LDS reads and forms all differences before the chain of dependent
+// adds (one LDS round trip per chunk, not per step).  Measured at 8 x 4K (planar layout, one wave
+// per plane, one chunk in flight: 0.36 ms grey, 0.99 ms colour): 0.33 / 0.83 ms; without the
+// global loads (timing-only build) 0.20 / 0.40 ms - the rest is the issue rate of the one wave a
+// SIMD holds when a grey batch gives every CU a single workgroup.  Capping the registers for a
+// third / fourth workgroup per CU spills and is slower.
 template <int R>
-__global__ __launch_bounds__(64) void gf_rowstate_kernel(const float *__restrict__ planes,
-                                                         double *__restrict__ states, int h, int w,
-                                                         int row_blocks, int np,
-                                                         const int *__restrict__ colour, int src_np,
-                                                         int nb)
+__global__ __launch_bounds__(256) void gf_rowstate_kernel(const float *__restrict__ planes,
+                                                          double *__restrict__ states, int h, int w,
+                                                          int row_blocks, int np,
+                                                          const int *__restrict__ colour, int src_np,
+                                                          int nb)
 {
     constexpr int KS = 2 * R + 1;
     constexpr int F = (KS + 15) & ~15;
     constexpr int NCH = F / 16;
     constexpr int PAD = (16 - R % 16) % 16;  // step t <-> extended index i = t - PAD, column i - R
     static_assert(KS + PAD <= 2 * F, "the window fills within the two peeled periods");
-    const int plane = blockIdx.x / row_blocks;
-    if (colour != nullptr && plane % np >= 4 && colour[plane / np] == 0)
+    const int ng = np / 4;                     // plane groups (src channels) per image
+    const int grp = blockIdx.x / row_blocks;   // plane group across the chunk of images
+    const int img = grp / ng, gq = grp - img * ng;
+    if (colour != nullptr && gq >= 1 && colour[img] == 0)
         return;  // grey 3-channel images only carry the 4 planes of their first channel
-    __shared__ float tE[kBRows][17];
+    __shared__ __align__(16) float tE[4][kBRows][20];  // pitch 20: 16-byte rows, conflict-free
 
-    const int lane = threadIdx.x;
-    const int row0 = (blockIdx.x - plane * row_blocks) * kBRows;
-    const float *S = planes + ((size_t)(plane / np) * src_np + plane % np) * h * w;
-    double *ST = states + (size_t)plane * nb * h + row0 + lane;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // the wave's plane of the group
+    const int row0 = (blockIdx.x - grp * row_blocks) * kBRows;
+    const float4 *S4 =
+        reinterpret_cast<const float4 *>(planes + ((size_t)img * src_np + gq * 4) * h * w);
+    double *ST = states + ((size_t)img * np + gq * 4 + wv) * nb * h + row0 + lane;
     const int total = w + 2 * R + PAD;  // steps
-    const int rr = lane >> 4, cc = lane & 15;
+    // loader role: the workgroup fetches the chunk's 64 rows x 16 columns as 1024 float4 (all
+    // four planes of a pixel), thread t the pixels t, t + 256, ...: 16 consecutive threads read
+    // 256 contiguous bytes of one image row
+    const int cc = tid & 15;
     const bool row_ok = row0 + lane < h;
-    uint32_t srow[16];
+    uint32_t srow[4];
 #pragma unroll
-    for (int k = 0; k < 16; k++)
-        srow[k] = (uint32_t)min(row0 + 4 * k + rr, h - 1) * (uint32_t)w;
+    for (int k = 0; k < 4; k++)
+        srow[k] = (uint32_t)min(row0 + ((tid + 256 * k) >> 4), h - 1) * (uint32_t)w;
 
-    float pre[16];
-#define RF_RS_FETCH(t0_)                                                                     \
+    // two chunks in flight (A: even chunks, B: odd ones): a workgroup walks its rows alone, one
+    // chunk after the other, so the time of a chunk is the memory latency it cannot hide
+    float4 preA[4], preB[4];
+    // (a chunk away from both ends of the row needs no border arithmetic; pixel offsets fit 32
+    //  bits - the host admits images below 2^28 pixels here - so a load is SGPR base + byte offset)
+#define RF_RS_FETCH(t0_, BUF)                                                                \
     do {                                                                                     \
-        const int sx_ = border_interpolate(min((t0_) + cc, total - 1) - PAD - R, w,          \
-                                           RF_BORDER_REFLECT);                               \
-        _Pragma("unroll") for (int k = 0; k < 16; k++) pre[k] = S[srow[k] + sx_];            \
+        const int x0_ = (t0_) - PAD - R;                                                     \
+        int sx_ = x0_ + cc;                                                                  \
+        if (x0_ < 0 || x0_ + 15 >= w || (t0_) + 15 >= total)                                 \
+            sx_ = border_interpolate(min((t0_) + cc, total - 1) - PAD - R, w,                \
+                                     RF_BORDER_REFLECT);                                     \
+        _Pragma("unroll") for (int k = 0; k < 4; k++) BUF[k] = *reinterpret_cast<const float4 *>( \
+            reinterpret_cast<const char *>(S4) + ((srow[k] + (uint32_t)sx_) << 4));          \
     } while (0)
     double s = 0.0;
     float fifo[F];
     // one chunk of 16 steps; PER = period (0, 1: peeled, window still filling; 2: steady state),
     // KCH = chunk of the period: step t = t0 + c with (t mod F) = KCH*16 + c static
-#define RF_RS_CHUNK(PER, KCH, t0_)                                                           \
+#define RF_RS_CHUNK(PER, KCH, t0_, BUF)                                                      \
     do {                                                                                     \
         const int t0c_ = (t0_);                                                              \
         if (t0c_ < total) {                                                                  \
             __syncthreads();                                                                 \
-            _Pragma("unroll") for (int k = 0; k < 16; k++) tE[4 * k + rr][cc] = pre[k];      \
+            _Pragma("unroll") for (int k = 0; k < 4; k++)                                    \
+            {                                                                                \
+                const int r_ = (tid + 256 * k) >> 4;                                         \
+                tE[0][r_][cc] = BUF[k].x;                                                    \
+                tE[1][r_][cc] = BUF[k].y;                                                    \
+                tE[2][r_][cc] = BUF[k].z;                                                    \
+                tE[3][r_][cc] = BUF[k].w;                                                    \
+            }                                                                                \
             __syncthreads();                                                                 \
-            if (t0c_ + 16 < total)                                                           \
-                RF_RS_FETCH(t0c_ + 16);                                                      \
+            if (t0c_ + 32 < total)                                                           \
+                RF_RS_FETCH(t0c_ + 32, BUF);                                                 \
+            if ((PER) == 2 && t0c_ + 16 <= total) {                                          \
+                /* full chunk in the steady state: the 16 operands first (16-byte LDS reads), */ \
+                /* the differences against the FIFO (the slot a step reads is overwritten    */ \
+                /* F - KS steps later), then the dependent adds: one LDS round trip per      */ \
+                /* chunk instead of one per step, no per-step branch                         */ \
+                float4 e4_[4];                                                               \
+                _Pragma("unroll") for (int c4 = 0; c4 < 4; c4++)                             \
+                    e4_[c4] = *reinterpret_cast<const float4 *>(&tE[wv][lane][4 * c4]);      \
+                const float e_[16] = {e4_[0].x, e4_[0].y, e4_[0].z, e4_[0].w, e4_[1].x, e4_[1].y, \
+                                      e4_[1].z, e4_[1].w, e4_[2].x, e4_[2].y, e4_[2].z, e4_[2].w, \
+                                      e4_[3].x, e4_[3].y, e4_[3].z, e4_[3].w};               \
+                _Pragma("unroll") for (int hh = 0; hh < 2; hh++)                             \
+                {                                                                            \
+                    double d_[8];                                                            \
+                    _Pragma("unroll") for (int c8 = 0; c8 < 8; c8++)                         \
+                        d_[c8] = (double)e_[8 * hh + c8] -                                   \
+                                 (double)fifo[((KCH) * 16 + 8 * hh + c8 + F - (KS % F)) % F]; \
+                    _Pragma("unroll") for (int c8 = 0; c8 < 8; c8++)                         \
+                    {                                                                        \
+                        const int c = 8 * hh + c8;                                           \
+                        s += d_[c8];                                                         \
+                        if (((c - PAD - KS + 1) & (kSB - 1)) == 0 && row_ok)                 \
+                            ST[(size_t)((t0c_ + c - PAD - KS + 1) >> 4) * h] = s;            \
+                    }                                                                        \
+                }                                                                            \
+                _Pragma("unroll") for (int c = 0; c < 16; c++) fifo[(KCH) * 16 + c] = e_[c]; \
+            } else                                                                           \
             _Pragma("unroll") for (int c = 0; c < 16; c++)                                   \
             {                                                                                \
                 const int tp_ = (KCH) * 16 + c;           /* t mod F */                      \
@@ -584,7 +650,7 @@ __global__ __launch_bounds__(64) void gf_rowstate_kernel(const float *__restrict
                 if ((PER) < 2 && ip_ < 0) {                                                  \
                     /* dummy step in front of the row */                                     \
                 } else if (t0c_ + c < total) {                                               \
-                    const float e_ = tE[lane][c];                                            \
+                    const float e_ = tE[wv][lane][c];                                        \
                     if ((PER) < 2 && ip_ < KS)                                               \
                         s += (double)e_;                                                     \
                     else                                                                     \
@@ -597,23 +663,34 @@ __global__ __launch_bounds__(64) void gf_rowstate_kernel(const float *__restrict
             }                                                                                \
         }                                                                                    \
     } while (0)
-#define RF_RS_PERIOD(PER, t0_)                                                               \
+    // P0 = buffer of the period's first chunk (chunks alternate A, B)
+#define RF_RS_PERIOD(PER, t0_, P0, P1)                                                       \
     do {                                                                                     \
-        RF_RS_CHUNK(PER, 0, (t0_));                                                          \
-        RF_RS_CHUNK(PER, 1, (t0_) + 16);                                                     \
-        RF_RS_CHUNK(PER, 2, (t0_) + 32);                                                     \
-        RF_RS_CHUNK(PER, 3, (t0_) + 48);                                                     \
-        RF_RS_CHUNK(PER, 4, (t0_) + 64);                                                     \
-        RF_RS_CHUNK(PER, 5, (t0_) + 80);                                                     \
+        RF_RS_CHUNK(PER, 0, (t0_), P0);                                                      \
+        RF_RS_CHUNK(PER, 1, (t0_) + 16, P1);                                                 \
+        RF_RS_CHUNK(PER, 2, (t0_) + 32, P0);                                                 \
+        RF_RS_CHUNK(PER, 3, (t0_) + 48, P1);                                                 \
+        RF_RS_CHUNK(PER, 4, (t0_) + 64, P0);                                                 \
+        RF_RS_CHUNK(PER, 5, (t0_) + 80, P1);                                                 \
         if constexpr (NCH > 6)                                                               \
-            RF_RS_CHUNK(PER, 6, (t0_) + 96);                                                 \
+            RF_RS_CHUNK(PER, 6, (t0_) + 96, P0);                                             \
     } while (0)
     static_assert(NCH == 6 || NCH == 7, "period of 96 or 112 steps");
-    RF_RS_FETCH(0);
-    RF_RS_PERIOD(0, 0);
-    RF_RS_PERIOD(1, F);
-    for (int t0 = 2 * F; t0 < total; t0 += F)
-        RF_RS_PERIOD(2, t0);
+    RF_RS_FETCH(0, preA);
+    RF_RS_FETCH(16, preB);
+    if constexpr (NCH == 6) {
+        RF_RS_PERIOD(0, 0, preA, preB);
+        RF_RS_PERIOD(1, F, preA, preB);
+        for (int t0 = 2 * F; t0 < total; t0 += F)
+            RF_RS_PERIOD(2, t0, preA, preB);
+    } else {  // 7 chunks per period: the buffers swap roles from one period to the next
+        RF_RS_PERIOD(0, 0, preA, preB);
+        RF_RS_PERIOD(1, F, preB, preA);
+        for (int t0 = 2 * F; t0 < total; t0 += 2 * F) {
+            RF_RS_PERIOD(2, t0, preA, preB);
+            RF_RS_PERIOD(2, t0 + F, preB, preA);
+        }
+    }
 #undef RF_RS_PERIOD
 #undef RF_RS_CHUNK
 #undef RF_RS_FETCH
@@ -656,7 +733,7 @@ __global__ __launch_bounds__(64) void gf_colwalk_kernel(
     __shared__ float stE[4 * T][kSB + 1], stL[4 * T][kSB + 1]; // operands [plane*T + row][col]
     __shared__ float xch[T][4][kSB];                          // means of the sub-tile's rows
     __shared__ int rowtab[2][T + 1];                          // image row of each padded row
-    __shared__ uint32_t rowoff[2][T + 1];                     // ... times 4 w (byte offset of the row in a plane)
+    __shared__ uint32_t rowoff[2][T + 1];                     // ... times 16 w (byte offset of the row in a plane group)
     __shared__ uint32_t gst[T][12];                           // guide bytes of the output rows
 
     const int lane = threadIdx.x;
@@ -670,13 +747,13 @@ __global__ __launch_bounds__(64) void gf_colwalk_kernel(
     const uint8_t *gimg = guide + (size_t)img * npx * 3;
     uint8_t *dimg = dst + (size_t)img * npx * SPX;
     // RowSum at output column o = 16 b + cc (cc >= 1):  + ext[o + 2r] - ext[o - 1], ext[i] = S[bi(i - r)]
-    // per-lane element offsets from the wave-uniform base abg (32 bits: the host admits images of
-    // less than 2^28 pixels here, so 4 planes stay below 2^30 elements); rowtab holds row * w
-    // (BYTE offsets, so that base + zero-extended offset is the whole address computation)
-    const uint32_t oe = 4u * ((uint32_t)g4 * (uint32_t)npx +
-                              (uint32_t)border_interpolate(b * kSB + cc + R, w, RF_BORDER_REFLECT));
-    const uint32_t ol = 4u * ((uint32_t)g4 * (uint32_t)npx +
-                              (uint32_t)border_interpolate(b * kSB + cc - 1 - R, w, RF_BORDER_REFLECT));
+    // per-lane BYTE offsets from the wave-uniform base abg of the channel's plane group
+    // ([h][w][4] floats; 32 bits: the host admits images of less than 2^28 pixels here), so that
+    // base + zero-extended (row offset + lane offset) is the whole address computation
+    const uint32_t oe = 4u * (uint32_t)g4 +
+                        16u * (uint32_t)border_interpolate(b * kSB + cc + R, w, RF_BORDER_REFLECT);
+    const uint32_t ol = 4u * (uint32_t)g4 +
+                        16u * (uint32_t)border_interpolate(b * kSB + cc - 1 - R, w, RF_BORDER_REFLECT);
     const char *abgb = reinterpret_cast<const char *>(abg);
     const double *Ps = stg + ((size_t)min(cp, 3) * nb + b) * h;
     const double scale = 1.0 / (double)(KS * KS);
@@ -694,7 +771,7 @@ __global__ __launch_bounds__(64) void gf_colwalk_kernel(
             const int row_ = border_interpolate(min((u_) * T + lane, jmax) - R, h,           \
                                                 RF_BORDER_REFLECT);                          \
             rowtab[(u_) & 1][lane] = row_;                                                   \
-            rowoff[(u_) & 1][lane] = 4u * (uint32_t)row_ * (uint32_t)w;                      \
+            rowoff[(u_) & 1][lane] = 16u * (uint32_t)row_ * (uint32_t)w;                     \
         }                                                                                    \
     } while (0)
 #define RF_FETCH(u_)                                                                         \
@@ -935,14 +1012,14 @@ int gf_f32_chunk(const float *guide, const float *src, float *dst, int m, int h,
         hipLaunchKernelGGL(gff_products_kernel<SCN>, dim3(pb, m), dim3(256), 0, stream, guide, s0, P,
                            npx);
         hipLaunchKernelGGL(gf_rowsum_kernel, dim3((unsigned)(m * NQ * row_blocks)), dim3(64), 0,
-                           stream, P, rows, h, w, radius, row_blocks, NQ, (const int *)nullptr, NQ);
+                           stream, P, rows, h, w, radius, row_blocks, NQ, (const int *)nullptr, NQ, 1);
         hipLaunchKernelGGL(gff_colsum_mean_kernel, dim3(ceil_div(w, 64), NQ, m), dim3(64), 0, stream,
                            rows, P, h, w, radius, NQ);
         hipLaunchKernelGGL(gff_algebra_kernel<SCN>, dim3(pb, m), dim3(256), 0, stream, P, npx, eps_f,
                            eps_small);
         hipLaunchKernelGGL(gf_rowsum_kernel, dim3((unsigned)(m * 4 * SCN * row_blocks)), dim3(64), 0,
                            stream, P, rows, h, w, radius, row_blocks, 4 * SCN,
-                           (const int *)nullptr, NQ);
+                           (const int *)nullptr, NQ, 1);
         hipLaunchKernelGGL((gf_colsum_apply_kernel<SCN, SCN, float>), dim3(ceil_div(w, 64), 1, m),
                            dim3(64, 4 * SCN), 0, stream, rows, guide, dst, h, w, radius,
                            (const int *)nullptr);
@@ -1092,11 +1169,11 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
             const int row_blocks = ceil_div(h, kBRows);
             if (fused) {
                 if (radius == 45)
-                    hipLaunchKernelGGL((gf_rowstate_kernel<45>), dim3((unsigned)(m * np * row_blocks)),
-                                       dim3(64), 0, st, ab, rows, h, w, row_blocks, np, colour, np, nb);
+                    hipLaunchKernelGGL((gf_rowstate_kernel<45>), dim3((unsigned)(m * src_cn * row_blocks)),
+                                       dim3(256), 0, st, ab, rows, h, w, row_blocks, np, colour, np, nb);
                 else
-                    hipLaunchKernelGGL((gf_rowstate_kernel<52>), dim3((unsigned)(m * np * row_blocks)),
-                                       dim3(64), 0, st, ab, rows, h, w, row_blocks, np, colour, np, nb);
+                    hipLaunchKernelGGL((gf_rowstate_kernel<52>), dim3((unsigned)(m * src_cn * row_blocks)),
+                                       dim3(256), 0, st, ab, rows, h, w, row_blocks, np, colour, np, nb);
                 const int it3 = m * 3 * nb, it1 = m * nb;
                 const dim3 g3(8 * (unsigned)ceil_div(it3, 8)), g1(8 * (unsigned)ceil_div(it1, 8));
 #define RF_GF_WALK(R, TT)                                                                             \
@@ -1119,7 +1196,7 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
                 continue;
             }
             hipLaunchKernelGGL(gf_rowsum_kernel, dim3((unsigned)(m * np * row_blocks)), dim3(64), 0,
-                               st, ab, rows, h, w, radius, row_blocks, np, colour, np);
+                               st, ab, rows, h, w, radius, row_blocks, np, colour, np, 4);
             dim3 gc(ceil_div(w, 64), 1, m);
             if (src_cn == 3) {
                 hipLaunchKernelGGL((gf_colsum_apply_kernel<3, 3>), gc, dim3(64, 12), 0, st, rows,
@@ -1133,17 +1210,18 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
         }
     };
 
-    // Optional (debug option "gf_two_streams"): a chunk of two or more images runs as two halves on
-    // two streams - the caller's and a side stream of the library, forked and joined with events,
-    // so the call still looks stream-ordered to the caller and can be captured into a graph.
-    // Measured at 8 x 4K: colour sources 8.7 % faster (stage 1 leaves 30 KB of LDS and a quarter
-    // of the registers of a CU free, which the other half's column-walk waves use), grey sources
-    // 2-5 % slower (their stage 1 fills the LDS; only the extra launches and tails remain).  The
-    // host cannot know which of the two a 3-channel buffer holds without a round trip, and the
-    // reference's guided filter runs on grey maps, so the default is one stream.
+    // A chunk of two or more images runs as two halves on two streams - the caller's and a side
+    // stream of the library, forked and joined with events, so the call still looks stream-ordered
+    // to the caller and can be captured into a graph.  The kernels of a pass are bound by different
+    // things (stage 1: latency at 3-4 waves per SIMD; row states: the latency of a chunk; column
+    // walk: the issue rate of its one wave per SIMD, which leaves half of a SIMD's registers
+    // free), and every launch ends in a tail of partly filled CUs: the other half's kernels fill
+    // both.  Measured (3 passes at 4K): 8 images grey 6.13 -> 6.08 ms, colour 14.0 -> 12.2 ms; 13
+    // images grey 10.8 -> 9.4 ms, colour 24.1 -> 19.9 ms.  The debug option "gf_one_stream" keeps
+    // everything on the caller's stream (cross-check; identical bytes).
     char *ws0 = static_cast<char *>(workspace) + header;
     hipStream_t side = nullptr;
-    if (fused && chunk >= 2 && debug_get(kDbgGfTwoStreams))
+    if (fused && chunk >= 2 && !debug_get(kDbgGfOneStream))
         side = gf_side_stream();
     for (int i0 = 0; i0 < n; i0 += chunk) {
         const int m = std::min(chunk, n - i0);

@@ -635,8 +635,8 @@ def test_captured_call_replays_the_chain(env):
 
 
 def test_captured_call_with_forked_guided_filter(env):
-    """With the debug option gf_two_streams the guided filter forks a side stream inside the call
-    and joins it before returning: the call can still be captured into a HIP graph, and the replay
+    """The guided filter forks a side stream inside the call for the second half of a batch and
+    joins it before returning: the call can still be captured into a HIP graph, and the replay
     gives the eager one-stream bytes (radius 45: fused stage 2, two images = two halves)."""
     from tests import synth
     rf, co, torch = env
@@ -645,12 +645,12 @@ def test_captured_call_with_forked_guided_filter(env):
     s = torch.from_numpy(np.stack([synth.scene_u8(h, w, seed=k) for k in (3, 4)])).cuda()
     out = torch.empty_like(s)
     ws = rf.ops.gf_workspace(2, h, w, 3, 45, s.device, torch)
-    want = rf.ops.guided_filter_u8(g, s, 45, 3.0, iterations=2)
-    with rf._ffi.debug_options(gf_two_streams=1):
-        cap = rf.ops.CapturedCall(lambda: rf.ops.guided_filter_u8(g, s, 45, 3.0, iterations=2,
-                                                                   out=out, workspace=ws))
-        got = cap.replay()
-        torch.cuda.synchronize()
+    with rf._ffi.debug_options(gf_one_stream=1):
+        want = rf.ops.guided_filter_u8(g, s, 45, 3.0, iterations=2)
+    cap = rf.ops.CapturedCall(lambda: rf.ops.guided_filter_u8(g, s, 45, 3.0, iterations=2,
+                                                               out=out, workspace=ws))
+    got = cap.replay()
+    torch.cuda.synchronize()
     assert torch.equal(got, want)
 
 
@@ -712,8 +712,8 @@ def test_gf_fused_stage2_in_place_chain_and_oracle(env, radius, eps):
     for seg_rows in (1, 17, 64, 1000):
         with rf._ffi.debug_options(gf_seg_rows=seg_rows):
             assert torch.equal(rf.ops.guided_filter_u8(g, s, radius, eps, iterations=3), got)
-    # the two images on two streams (forked and joined inside the call)
-    with rf._ffi.debug_options(gf_two_streams=1):
+    # everything on the caller's stream (the default forks a side stream for the second image)
+    with rf._ffi.debug_options(gf_one_stream=1):
         assert torch.equal(rf.ops.guided_filter_u8(g, s, radius, eps, iterations=3), got)
     one = rf._ffi.load_library().rf_gf_workspace_bytes(1, h, w, 3, 3, radius)
     ws = torch.empty(one, dtype=torch.uint8, device="cuda")

@@ -77,12 +77,12 @@ def main():
     res = {}
     for tag, src in (("grey", grey), ("colour", scene)):
         for iters in (1, 3):
-            t = {"fused": [], "fused_two_streams": [], "two_kernel": []}
+            t = {"fused": [], "fused_one_stream": [], "two_kernel": []}
             for _ in range(args.rounds + 1):
                 t["fused"].append(timed(lambda: rf.ops.guided_filter_u8(flat, src, 45, 3.0,
                                                                         iterations=iters, out=dst)))
-                with _ffi.debug_options(gf_two_streams=1):
-                    t["fused_two_streams"].append(timed(lambda: rf.ops.guided_filter_u8(
+                with _ffi.debug_options(gf_one_stream=1):
+                    t["fused_one_stream"].append(timed(lambda: rf.ops.guided_filter_u8(
                         flat, src, 45, 3.0, iterations=iters, out=dst)))
                 with _ffi.debug_options(gf_two_kernel=1):
                     t["two_kernel"].append(timed(lambda: rf.ops.guided_filter_u8(
