@@ -358,11 +358,11 @@ constexpr int kBChunk = 32;
 // planes: [img][src_np][h][w] (il = 1) or [img][src_np / 4][h][w][4] (il = 4: groups of four
 // planes interleaved per pixel, the layout stage 1 writes), of which the first np per image are
 // summed; rowsums: [img][np][h][w]
+template <int il>
 __global__ __launch_bounds__(64) void gf_rowsum_kernel(const float *__restrict__ planes,
                                                        double *__restrict__ rowsums, int h, int w,
                                                        int radius, int row_blocks, int np,
-                                                       const int *__restrict__ colour, int src_np,
-                                                       int il)
+                                                       const int *__restrict__ colour, int src_np)
 {
     {
         // grey 3-channel images only carry the 4 planes of their first channel
@@ -1011,15 +1011,15 @@ int gf_f32_chunk(const float *guide, const float *src, float *dst, int m, int h,
         const float *s0 = it == 0 ? src : dst;
         hipLaunchKernelGGL(gff_products_kernel<SCN>, dim3(pb, m), dim3(256), 0, stream, guide, s0, P,
                            npx);
-        hipLaunchKernelGGL(gf_rowsum_kernel, dim3((unsigned)(m * NQ * row_blocks)), dim3(64), 0,
-                           stream, P, rows, h, w, radius, row_blocks, NQ, (const int *)nullptr, NQ, 1);
+        hipLaunchKernelGGL(gf_rowsum_kernel<1>, dim3((unsigned)(m * NQ * row_blocks)), dim3(64), 0,
+                           stream, P, rows, h, w, radius, row_blocks, NQ, (const int *)nullptr, NQ);
         hipLaunchKernelGGL(gff_colsum_mean_kernel, dim3(ceil_div(w, 64), NQ, m), dim3(64), 0, stream,
                            rows, P, h, w, radius, NQ);
         hipLaunchKernelGGL(gff_algebra_kernel<SCN>, dim3(pb, m), dim3(256), 0, stream, P, npx, eps_f,
                            eps_small);
-        hipLaunchKernelGGL(gf_rowsum_kernel, dim3((unsigned)(m * 4 * SCN * row_blocks)), dim3(64), 0,
+        hipLaunchKernelGGL(gf_rowsum_kernel<1>, dim3((unsigned)(m * 4 * SCN * row_blocks)), dim3(64), 0,
                            stream, P, rows, h, w, radius, row_blocks, 4 * SCN,
-                           (const int *)nullptr, NQ, 1);
+                           (const int *)nullptr, NQ);
         hipLaunchKernelGGL((gf_colsum_apply_kernel<SCN, SCN, float>), dim3(ceil_div(w, 64), 1, m),
                            dim3(64, 4 * SCN), 0, stream, rows, guide, dst, h, w, radius,
                            (const int *)nullptr);
@@ -1195,8 +1195,8 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
 #undef RF_GF_WALK
                 continue;
             }
-            hipLaunchKernelGGL(gf_rowsum_kernel, dim3((unsigned)(m * np * row_blocks)), dim3(64), 0,
-                               st, ab, rows, h, w, radius, row_blocks, np, colour, np, 4);
+            hipLaunchKernelGGL(gf_rowsum_kernel<4>, dim3((unsigned)(m * np * row_blocks)), dim3(64), 0,
+                               st, ab, rows, h, w, radius, row_blocks, np, colour, np);
             dim3 gc(ceil_div(w, 64), 1, m);
             if (src_cn == 3) {
                 hipLaunchKernelGGL((gf_colsum_apply_kernel<3, 3>), gc, dim3(64, 12), 0, st, rows,

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Run the guided filter a few times at 4K (for rocprofv3 --kernel-trace --stats / --pmc).
 
-    python3 tools/gf_profile.py [batch] [h w] [grey|colour] [iterations]
+    python3 tools/gf_profile.py [batch] [h w] [grey|colour] [iterations] [wall]
+(`wall`: also write the wall time of a call to gpurun_out/gf_profile_wall_<kind>.json)
 """
 import os
 import sys
@@ -20,6 +21,19 @@ scene, grey = bench.synth_batch(torch, n, h, w, 5000, dev)
 flat = (scene // 32) * 32 + 16
 src = grey if kind == "grey" else scene
 dst = torch.empty_like(src)
+wall = []
 for _ in range(3):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     rf.ops.guided_filter_u8(flat, src, 45, 3.0, iterations=iters, out=dst)
-torch.cuda.synchronize()
+    e1.record()
+    torch.cuda.synchronize()
+    wall.append(e0.elapsed_time(e1))
+# wall time of a call (the two halves of the batch overlap on two streams, so the kernels'
+# durations do not add up to it); the first call also uploads nothing new after the warm-up below
+out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+if os.path.isdir(out) and len(sys.argv) > 6 and sys.argv[6] == "wall":
+    import json
+    with open(os.path.join(out, "gf_profile_wall_%s.json" % kind), "w") as fh:
+        json.dump({"kind": kind, "batch": n, "h": h, "w": w, "iterations": iters,
+                   "wall_ms": sorted(wall)[1]}, fh)

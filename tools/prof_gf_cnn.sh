@@ -24,8 +24,9 @@ run() {  # name, pmc-or-empty, program...
     fi
 }
 for pmc in "" FETCH_SIZE WRITE_SIZE; do
-    run gf "$pmc" python3 tools/gf_profile.py "$NB" 2160 3840 grey
-    run gfc "$pmc" python3 tools/gf_profile.py "$NB" 2160 3840 colour
+    WALL=$([ -z "$pmc" ] && echo wall || echo nowall)  # counter passes serialise the kernels
+    run gf "$pmc" python3 tools/gf_profile.py "$NB" 2160 3840 grey 1 $WALL
+    run gfc "$pmc" python3 tools/gf_profile.py "$NB" 2160 3840 colour 1 $WALL
     run cnn "$pmc" python3 tools/cnn_profile.py 256
 done
 ls "$OUT"
