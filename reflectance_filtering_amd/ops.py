@@ -51,7 +51,8 @@ def joint_bilateral_u8(joint, src, d, sigma_color, sigma_space, border=_ffi.BORD
 def gf_workspace(n, h, w, scn, radius, device, torch):
     """Guided-filter scratch for the CURRENT stream of `device`, cached per (device, stream):
     two streams (or threads with their own streams) never share planes.  The cache keeps one
-    buffer per key, sized by rf_gf_workspace_bytes (capped at 6 GiB); release_workspaces()
+    buffer per key, sized by rf_gf_workspace_bytes (capped at 1/16 of the device's memory, at most
+    16 GiB); release_workspaces()
     drops them."""
     lib = _ffi.load_library()
     need = lib.rf_gf_workspace_bytes(n, h, w, 3, scn, radius)
