@@ -236,9 +236,9 @@ __global__ __launch_bounds__(kCnnThreads) void cnn_reflectance_kernel(
 // next layer's {pixel 0, pixel 1} pairs directly.  Against the LDS-column form this drops the 32
 // KB of LDS per workgroup, the write/read of every activation through it and the duplicating
 // moves: ~170 VGPRs and nothing else limiting occupancy, i.e. three waves per SIMD instead of two.
-// The layer loop stays rolled (input pairs A, output pairs B, 32 moves B -> A per layer): unrolled,
-// hipcc gives every layer's outputs registers of their own (+64 per layer) and the kernel drops
-// to one wave per SIMD.  Every scalar load is an asm statement at an immediate offset from a
+// The layer loop stays rolled, two layers per iteration ping-ponging between the pair sets A and
+// B: fully unrolled, hipcc gives every layer's outputs registers of their own (+64 per layer) and
+// the kernel drops to one wave per SIMD.  Every scalar load is an asm statement at an immediate offset from a
 // per-layer base: plain loads are hoisted together and spill the SGPR file.
 // ------------------------------------------------------------------------------------------
 #define RF_PKFMA_P0(ACC, W2, IN)                                                              \
@@ -258,53 +258,97 @@ __device__ __forceinline__ void finish_pair(const float2v &acc0, const float2v &
     out_odd = float2v{fmaxf(__fadd_rn(acc0.y, by), 0.f), fmaxf(__fadd_rn(acc1.y, by), 0.f)};
 }
 
+// first term of a chain: fma(w, x, +0) == w * x (the product rounded once), so the chain starts
+// with a packed multiply and the accumulators need no zeroing
+#define RF_PKMUL_P0(ACC, W2, IN)                                                              \
+    asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(ACC) : "s"(W2), "v"(IN))
+#define RF_PKMUL_P1(ACC, W2, IN)                                                              \
+    asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(ACC) : "s"(W2), "v"(IN))
+
 // A 32-input layer: in[k] = {px0, px1} of input channel k, out[c] likewise.  rec = the layer's 16
 // records of kRec floats (buffer A: k = 0..15 of a channel pair, buffer B: k = 16..31 + biases).
+// Bias + ReLU of channel pair o (2 packed adds, 4 max: "simple" 2-cycle instructions) are spread
+// over the FMA stream of pair o + 1, where each rides in the issue window of a packed FMA
+// (tools/microbench/valu_rates2.hip) instead of costing 16 cycles in a row after every pair;
+// accumulators and biases alternate between two register sets by the parity of o.
 __device__ __forceinline__ void layer32_regs(const float *__restrict__ rec, const float2v (&in)[32],
                                              float2v (&out)[32])
 {
     float16v a0, a1, b0, b1;
-    float2v bias;
+    float2v accE0, accE1, accO0, accO1;  // {channel 2o, 2o+1} of pixel 0 / pixel 1, even / odd o
+    float2v biasE, biasO;
+    float2v tf0, tf1;                    // accumulators + bias of the pair being finished
 #define RF_SLOAD16(DST, PTR, OFF) \
     asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(DST) : "s"(PTR), "n"(OFF))
 #define RF_SLOAD2(DST, PTR, OFF) \
     asm volatile("s_load_dwordx2 %0, %1, %2" : "=s"(DST) : "s"(PTR), "n"(OFF))
-#define RF_FMA16R(W0, W1, KBASE)                                                             \
+    // one sixth of the finish of pair PO (accumulators PA0 / PA1, biases PB)
+#define RF_FIN(STEP, PO, PA0, PA1, PB)                                                       \
+    do {                                                                                     \
+        if ((STEP) == 0)                                                                     \
+            tf0 = PA0 + PB;                                                                  \
+        if ((STEP) == 1)                                                                     \
+            tf1 = PA1 + PB;                                                                  \
+        if ((STEP) == 2)                                                                     \
+            out[2 * (PO)].x = fmaxf(tf0.x, 0.f);                                             \
+        if ((STEP) == 3)                                                                     \
+            out[2 * (PO)].y = fmaxf(tf1.x, 0.f);                                             \
+        if ((STEP) == 4)                                                                     \
+            out[2 * (PO) + 1].x = fmaxf(tf0.y, 0.f);                                         \
+        if ((STEP) == 5)                                                                     \
+            out[2 * (PO) + 1].y = fmaxf(tf1.y, 0.f);                                         \
+    } while (0)
+    // 16 inputs of a pair; FIRST: the chain starts here; FIN0: first finish step placed in this half
+#define RF_FMA16R(ACC0, ACC1, W0, W1, KBASE, FIRST, DOFIN, FIN0, PO, PA0, PA1, PB)           \
     _Pragma("unroll") for (int k = 0; k < 8; k++)                                            \
     {                                                                                        \
         const float2v w2 = float2v{W0[2 * k], W0[2 * k + 1]};                                \
-        RF_PKFMA_P0(acc0, w2, in[(KBASE) + k]);                                              \
-        RF_PKFMA_P1(acc1, w2, in[(KBASE) + k]);                                              \
+        if ((FIRST) && k == 0) {                                                             \
+            RF_PKMUL_P0(ACC0, w2, in[(KBASE) + k]);                                          \
+            RF_PKMUL_P1(ACC1, w2, in[(KBASE) + k]);                                          \
+        } else {                                                                             \
+            RF_PKFMA_P0(ACC0, w2, in[(KBASE) + k]);                                          \
+            RF_PKFMA_P1(ACC1, w2, in[(KBASE) + k]);                                          \
+        }                                                                                    \
+        if ((DOFIN) && (k == 2 || k == 4 || k == 6))                                         \
+            RF_FIN((FIN0) + (k - 2) / 2, PO, PA0, PA1, PB);                                  \
     }                                                                                        \
     _Pragma("unroll") for (int k = 0; k < 8; k++)                                            \
     {                                                                                        \
         const float2v w2 = float2v{W1[2 * k], W1[2 * k + 1]};                                \
-        RF_PKFMA_P0(acc0, w2, in[(KBASE) + 8 + k]);                                          \
-        RF_PKFMA_P1(acc1, w2, in[(KBASE) + 8 + k]);                                          \
+        RF_PKFMA_P0(ACC0, w2, in[(KBASE) + 8 + k]);                                          \
+        RF_PKFMA_P1(ACC1, w2, in[(KBASE) + 8 + k]);                                          \
     }
     RF_SLOAD16(a0, rec, 0);
     RF_SLOAD16(a1, rec, 64);
-#define RF_OP(OP)                                                                            \
+    // pair OP accumulates in CUR*, pair OP - 1 (PRV*) is finished meanwhile
+#define RF_OP(OP, CUR0, CUR1, CURB, PRV0, PRV1, PRVB)                                        \
     {                                                                                        \
         constexpr int cur_ = (OP) * kRec * 4;                                                \
         constexpr int nxt_ = ((OP) < 15 ? (OP) + 1 : (OP)) * kRec * 4;                       \
-        float2v acc0 = float2v{0.f, 0.f}, acc1 = float2v{0.f, 0.f};                          \
         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1));                           \
         RF_SLOAD16(b0, rec, cur_ + 128);                                                     \
         RF_SLOAD16(b1, rec, cur_ + 192);                                                     \
-        RF_SLOAD2(bias, rec, cur_ + 256);                                                    \
-        RF_FMA16R(a0, a1, 0)                                                                 \
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b0), "+s"(b1), "+s"(bias));               \
+        RF_SLOAD2(CURB, rec, cur_ + 256);                                                    \
+        RF_FMA16R(CUR0, CUR1, a0, a1, 0, true, (OP) > 0, 0, (OP) - 1, PRV0, PRV1, PRVB)      \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b0), "+s"(b1), "+s"(CURB));               \
         RF_SLOAD16(a0, rec, nxt_);                                                           \
         RF_SLOAD16(a1, rec, nxt_ + 64);                                                      \
-        RF_FMA16R(b0, b1, 16)                                                                \
-        finish_pair(acc0, acc1, bias.x, bias.y, out[2 * (OP)], out[2 * (OP) + 1]);           \
+        RF_FMA16R(CUR0, CUR1, b0, b1, 16, false, (OP) > 0, 3, (OP) - 1, PRV0, PRV1, PRVB)    \
     }
-    RF_OP(0) RF_OP(1) RF_OP(2) RF_OP(3) RF_OP(4) RF_OP(5) RF_OP(6) RF_OP(7)
-    RF_OP(8) RF_OP(9) RF_OP(10) RF_OP(11) RF_OP(12) RF_OP(13) RF_OP(14) RF_OP(15)
+#define RF_OP_E(OP) RF_OP(OP, accE0, accE1, biasE, accO0, accO1, biasO)
+#define RF_OP_O(OP) RF_OP(OP, accO0, accO1, biasO, accE0, accE1, biasE)
+    RF_OP_E(0) RF_OP_O(1) RF_OP_E(2) RF_OP_O(3) RF_OP_E(4) RF_OP_O(5) RF_OP_E(6) RF_OP_O(7)
+    RF_OP_E(8) RF_OP_O(9) RF_OP_E(10) RF_OP_O(11) RF_OP_E(12) RF_OP_O(13) RF_OP_E(14) RF_OP_O(15)
+#undef RF_OP_O
+#undef RF_OP_E
 #undef RF_OP
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a0), "+s"(a1));
+#pragma unroll
+    for (int st = 0; st < 6; st++)
+        RF_FIN(st, 15, accO0, accO1, biasO);
 #undef RF_FMA16R
+#undef RF_FIN
 #undef RF_SLOAD2
 #undef RF_SLOAD16
 }
@@ -384,13 +428,14 @@ __global__ __launch_bounds__(kCnnThreads) void cnn_reflectance_regs_kernel(
             }
         }
         fuse32(A, wf, z);
+        // the four 32 -> 32 layers ping-pong between A and B: no copies, and one rolled loop of two
+        // iterations keeps hipcc from giving every layer's outputs registers of their own
 #pragma unroll 1
-        for (int l = 0; l < 4; l++) {
+        for (int l = 0; l < 4; l += 2) {
             layer32_regs(packed + 128 + l * 1056, A, B);
             fuse32(B, wf + 32 * (l + 1), z);
-#pragma unroll
-            for (int c = 0; c < 32; c++)
-                A[c] = B[c];
+            layer32_regs(packed + 128 + (l + 1) * 1056, B, A);
+            fuse32(A, wf + 32 * (l + 2), z);
         }
 #pragma unroll
         for (int p = 0; p < kPxPerLane; p++) {
@@ -409,6 +454,8 @@ __global__ __launch_bounds__(kCnnThreads) void cnn_reflectance_regs_kernel(
 }
 #undef RF_PKFMA_P0
 #undef RF_PKFMA_P1
+#undef RF_PKMUL_P0
+#undef RF_PKMUL_P1
 
 // One packed copy of the weights per (device, stream): a call re-packs the caller's weights on
 // its own stream (18 tiny workgroups; the weights may have changed since the last call), so calls
