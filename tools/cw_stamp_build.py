@@ -34,17 +34,15 @@ rep('''        double s_ = pst;                                                 
         const unsigned long long t1_ = __builtin_amdgcn_s_memtime();                         \\
         if (!(FILL))''')
 rep('''        if (chain) {                                                                         \\
-            Rt[cp * kSB][cl] = s_;''', '''        const unsigned long long t2_ = __builtin_amdgcn_s_memtime();                         \\
+            /* all operand differences first''', '''        const unsigned long long t2_ = __builtin_amdgcn_s_memtime();                         \\
         if (chain) {                                                                         \\
-            Rt[cp * kSB][cl] = s_;''')
+            /* all operand differences first''')
 rep('''        __syncthreads();                                                                     \\
-        _Pragma("unroll") for (int jj = 0; jj < T; jj++)                                     \\
         {                                                                                    \\
-            const double v_ = Rt[lane][jj];''', '''        __syncthreads();                                                                     \\
+            /* the sub-tile's row sums first''', '''        __syncthreads();                                                                     \\
         const unsigned long long t3_ = __builtin_amdgcn_s_memtime();                         \\
-        _Pragma("unroll") for (int jj = 0; jj < T; jj++)                                     \\
         {                                                                                    \\
-            const double v_ = Rt[lane][jj];''')
+            /* the sub-tile's row sums first''')
 rep('''        if (!(FILL)) {                                                                       \\
             _Pragma("unroll") for (int k = 0; k < NG; k++)''', '''        const unsigned long long t4_ = __builtin_amdgcn_s_memtime();                         \\
         acc_st[0] += t1_ - t0_; acc_st[1] += t2_ - t1_; acc_st[2] += t3_ - t2_; acc_st[3] += t4_ - t3_; \\
