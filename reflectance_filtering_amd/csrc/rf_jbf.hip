@@ -615,7 +615,9 @@ __device__ __forceinline__ void jbf_tap_loop_grey4(uint32_t lut_lane_addr, uint3
         ngroups_out = (hw4 >> 1) + 1;
     };
 
-    uint32_t tq[4];
+    // look-ahead texels of columns 0..3 of a group as two register pairs: columns (0, 1) and
+    // (2, 3) are each fetched by one ds_read2_b32 (their tile addresses differ by Q4 texels)
+    uint2v tp[2];
     float4v wna, wnb;
     float gg[2][kPix];
     uint32_t ta, wa_addr;
@@ -623,17 +625,14 @@ __device__ __forceinline__ void jbf_tap_loop_grey4(uint32_t lut_lane_addr, uint3
     row_addr(-radius, ta, wa_addr, ngroups);
     // prologue of the first tap row: texels of columns 0 and 1, weight window of group 0,
     // gathers of column 0.  Every later row gets these from the last group of the row before.
-    asm volatile("ds_read_b32 %0, %2\n\t"
-                 "ds_read_b32 %1, %2 offset:%3"
-                 : "=&v"(tq[0]), "=&v"(tq[1])
-                 : "v"(ta), "n"(Q4 * 4));
+    asm volatile("ds_read2_b32 %0, %1 offset1:%2" : "=&v"(tp[0]) : "v"(ta), "n"(Q4));
     asm volatile("ds_read_b128 %0, %2\n\t"
                  "ds_read_b128 %1, %2 offset:16"
                  : "=&v"(wna), "=&v"(wnb)
                  : "v"(wa_addr));
-    asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(tq[0]));
+    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(tp[0]));
     {
-        const uint32_t tj = tq[0] & mask;
+        const uint32_t tj = tp[0].x & mask;
 #pragma unroll
         for (int p = 0; p < kPix; p++) {
             const uint32_t a =
@@ -643,17 +642,30 @@ __device__ __forceinline__ void jbf_tap_loop_grey4(uint32_t lut_lane_addr, uint3
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(tq[1]), "+v"(wna), "+v"(wnb), "+v"(gg[0][0]), "+v"(gg[0][1]),
+                 : "+v"(tp[0]), "+v"(wna), "+v"(wnb), "+v"(gg[0][0]), "+v"(gg[0][1]),
                    "+v"(gg[0][2]), "+v"(gg[0][3]));
 
+    // even steps fetch the texels of two columns (this step's look-ahead and the next step's);
+    // the pair is an output of the even steps only
+#define RF_TQ(U) tp[((U) & 3) >> 1][(U) & 1]
+#define RF_G4_TNOUT(U) RF_G4_TNOUT_##U
+#define RF_G4_TNOUT_0 [tn] "=&v"(tp[1]),
+#define RF_G4_TNOUT_2 [tn] "=&v"(tp[0]),
+#define RF_G4_TNOUT_1
+#define RF_G4_TNOUT_3
+#define RF_G4_READ(U) RF_G4_READ_##U
+#define RF_G4_READ_0 "ds_read2_b32 %[tn], %[ta] offset0:%[o0] offset1:%[o1]\n\t"
+#define RF_G4_READ_2 "ds_read2_b32 %[tn], %[ta] offset0:%[o0] offset1:%[o1]\n\t"
+#define RF_G4_READ_1 ""
+#define RF_G4_READ_3 ""
 #define RF_TEXEL_OFF4(U) (((((U) + 2) & 3) * Q4 + (((U) + 2) >> 2)) * 4)
     // Column step U of a group: texel of column +2 (from address TA + OFF), SAD + gathers of
     // column +1, accumulation of column +0.  GA = gathers being consumed, GB = gathers being
     // issued (their registers first hold alpha, then the LDS address, then the LUT value).
-#define RF_G4_PART1(U, GA, GB, TA, OFF)                                                          \
+#define RF_G4_PART1(U, GA, GB, TA, OFF, OFF1)                                                          \
     float w0_, w1_, w2_, w3_, s_;                                                                \
     uint32_t tj_;                                                                                \
-    asm volatile("ds_read_b32 %[tn], %[ta] offset:%[off]\n\t"                                    \
+    asm volatile(RF_G4_READ(U)                                                                   \
                  "v_and_b32 %[tj], %[mask], %[t1]\n\t"                                           \
                  "v_sad_u8 %[a0], %[tj], %[jc0], 0\n\t"                                          \
                  "v_mul_f32 %[w0], %[wv0], %[g0]\n\t"                                            \
@@ -664,11 +676,11 @@ __device__ __forceinline__ void jbf_tap_loop_grey4(uint32_t lut_lane_addr, uint3
                  "v_sad_u8 %[a3], %[tj], %[jc3], 0\n\t"                                          \
                  "v_mul_f32 %[w3], %[wv3], %[g3]\n\t"                                            \
                  "v_cvt_f32_ubyte3 %[s], %[t0]"                                                  \
-                 : [tn] "=&v"(tq[((U) + 2) & 3]), [tj] "=&v"(tj_), [a0] "=&v"(GB[0]),            \
+                 : RF_G4_TNOUT(U)[tj] "=&v"(tj_), [a0] "=&v"(GB[0]),                             \
                    [a1] "=&v"(GB[1]), [a2] "=&v"(GB[2]), [a3] "=&v"(GB[3]), [w0] "=&v"(w0_),     \
                    [w1] "=&v"(w1_), [w2] "=&v"(w2_), [w3] "=&v"(w3_), [s] "=&v"(s_)              \
-                 : [ta] "v"(TA), [off] "n"(OFF), [mask] "v"(mask),                               \
-                   [t1] "v"(tq[((U) + 1) & 3]), [t0] "v"(tq[(U)]), [jc0] "v"(jc[0]),             \
+                 : [ta] "v"(TA), [o0] "n"((OFF) / 4), [o1] "n"((OFF1) / 4), [mask] "v"(mask),    \
+                   [t1] "v"(RF_TQ((U) + 1)), [t0] "v"(RF_TQ(U)), [jc0] "v"(jc[0]),               \
                    [jc1] "v"(jc[1]), [jc2] "v"(jc[2]), [jc3] "v"(jc[3]), [wv0] "v"(wv[4 - (U)]), \
                    [wv1] "v"(wv[5 - (U)]), [wv2] "v"(wv[6 - (U)]), [wv3] "v"(wv[7 - (U)]),       \
                    [g0] "v"(GA[0]), [g1] "v"(GA[1]), [g2] "v"(GA[2]), [g3] "v"(GA[3]));          \
@@ -691,10 +703,10 @@ __device__ __forceinline__ void jbf_tap_loop_grey4(uint32_t lut_lane_addr, uint3
                    [w2] "v"(w2_), [w3] "v"(w3_));
     // the same step for a single-channel joint (J1): the SAD of the pre-scaled values plus the
     // lane's LUT address is the gather address
-#define RF_G4_PART1_J1(U, GA, GB, TA, OFF)                                                       \
+#define RF_G4_PART1_J1(U, GA, GB, TA, OFF, OFF1)                                                       \
     float w0_, w1_, w2_, w3_, s_;                                                                \
     uint32_t tj_;                                                                                \
-    asm volatile("ds_read_b32 %[tn], %[ta] offset:%[off]\n\t"                                    \
+    asm volatile(RF_G4_READ(U)                                                                   \
                  "v_and_b32 %[tj], %[mask], %[t1]\n\t"                                           \
                  "v_sad_u32 %[a0], %[tj], %[jc0], %[la]\n\t"                                     \
                  "v_mul_f32 %[w0], %[wv0], %[g0]\n\t"                                            \
@@ -705,11 +717,12 @@ __device__ __forceinline__ void jbf_tap_loop_grey4(uint32_t lut_lane_addr, uint3
                  "v_sad_u32 %[a3], %[tj], %[jc3], %[la]\n\t"                                     \
                  "v_mul_f32 %[w3], %[wv3], %[g3]\n\t"                                            \
                  "v_cvt_f32_ubyte3 %[s], %[t0]"                                                  \
-                 : [tn] "=&v"(tq[((U) + 2) & 3]), [tj] "=&v"(tj_), [a0] "=&v"(GB[0]),            \
+                 : RF_G4_TNOUT(U)[tj] "=&v"(tj_), [a0] "=&v"(GB[0]),                             \
                    [a1] "=&v"(GB[1]), [a2] "=&v"(GB[2]), [a3] "=&v"(GB[3]), [w0] "=&v"(w0_),     \
                    [w1] "=&v"(w1_), [w2] "=&v"(w2_), [w3] "=&v"(w3_), [s] "=&v"(s_)              \
-                 : [ta] "v"(TA), [off] "n"(OFF), [mask] "v"(mask), [la] "v"(lut_lane_addr),      \
-                   [t1] "v"(tq[((U) + 1) & 3]), [t0] "v"(tq[(U)]), [jc0] "v"(jc[0]),             \
+                 : [ta] "v"(TA), [o0] "n"((OFF) / 4), [o1] "n"((OFF1) / 4), [mask] "v"(mask),    \
+                   [la] "v"(lut_lane_addr),                                                      \
+                   [t1] "v"(RF_TQ((U) + 1)), [t0] "v"(RF_TQ(U)), [jc0] "v"(jc[0]),               \
                    [jc1] "v"(jc[1]), [jc2] "v"(jc[2]), [jc3] "v"(jc[3]), [wv0] "v"(wv[4 - (U)]), \
                    [wv1] "v"(wv[5 - (U)]), [wv2] "v"(wv[6 - (U)]), [wv3] "v"(wv[7 - (U)]),       \
                    [g0] "v"(GA[0]), [g1] "v"(GA[1]), [g2] "v"(GA[2]), [g3] "v"(GA[3]));          \
@@ -757,22 +770,22 @@ __device__ __forceinline__ void jbf_tap_loop_grey4(uint32_t lut_lane_addr, uint3
             wv[0] = wna.x; wv[1] = wna.y; wv[2] = wna.z; wv[3] = wna.w;                             \
             wv[4] = wnb.x; wv[5] = wnb.y; wv[6] = wnb.z; wv[7] = wnb.w;                             \
             {                                                                                       \
-                P1(0, gg[0], gg[1], ta, RF_TEXEL_OFF4(0))                                           \
-                RF_G4_PART2(tq[2], gg[1], )                                                         \
+                P1(0, gg[0], gg[1], ta, RF_TEXEL_OFF4(0), RF_TEXEL_OFF4(1))                         \
+                RF_G4_PART2(tp[1], gg[1], )                                                         \
             }                                                                                       \
             {                                                                                       \
-                P1(1, gg[1], gg[0], ta, RF_TEXEL_OFF4(1))                                           \
-                RF_G4_PART2(tq[3], gg[0], )                                                         \
+                P1(1, gg[1], gg[0], ta, 0, 0)                                                       \
+                RF_G4_PART2(tp[1], gg[0], )                                                         \
             }                                                                                       \
             {                                                                                       \
-                P1(2, gg[0], gg[1], ta, RF_TEXEL_OFF4(2))                                           \
-                RF_G4_PART2(tq[0], gg[1], )                                                         \
+                P1(2, gg[0], gg[1], ta, RF_TEXEL_OFF4(2), RF_TEXEL_OFF4(3))                         \
+                RF_G4_PART2(tp[0], gg[1], )                                                         \
             }                                                                                       \
             {                                                                                       \
-                P1(3, gg[1], gg[0], ta, RF_TEXEL_OFF4(3))                                           \
+                P1(3, gg[1], gg[0], ta, 0, 0)                                                       \
                 wa_addr -= 16;                                                                      \
                 RF_LOAD_WINDOW(wa_addr)                                                             \
-                RF_G4_PART2(tq[1], gg[0], RF_COMMA_W)                                               \
+                RF_G4_PART2(tp[0], gg[0], RF_COMMA_W)                                               \
             }                                                                                       \
             ta += 4;                                                                                \
         }                                                                                           \
@@ -781,21 +794,21 @@ __device__ __forceinline__ void jbf_tap_loop_grey4(uint32_t lut_lane_addr, uint3
             wv[0] = wna.x; wv[1] = wna.y; wv[2] = wna.z; wv[3] = wna.w;                             \
             wv[4] = wnb.x; wv[5] = wnb.y; wv[6] = wnb.z; wv[7] = wnb.w;                             \
             {                                                                                       \
-                P1(0, gg[0], gg[1], ta, RF_TEXEL_OFF4(0))                                           \
-                RF_G4_PART2(tq[2], gg[1], )                                                         \
+                P1(0, gg[0], gg[1], ta, RF_TEXEL_OFF4(0), RF_TEXEL_OFF4(1))                         \
+                RF_G4_PART2(tp[1], gg[1], )                                                         \
             }                                                                                       \
             {                                                                                       \
-                P1(1, gg[1], gg[0], ta, RF_TEXEL_OFF4(1))                                           \
-                RF_G4_PART2(tq[3], gg[0], )                                                         \
+                P1(1, gg[1], gg[0], ta, 0, 0)                                                       \
+                RF_G4_PART2(tp[1], gg[0], )                                                         \
             }                                                                                       \
             {                                                                                       \
-                P1(2, gg[0], gg[1], ta_next, 0)                                                     \
-                RF_G4_PART2(tq[0], gg[1], )                                                         \
+                P1(2, gg[0], gg[1], ta_next, 0, Q4 * 4)                                             \
+                RF_G4_PART2(tp[0], gg[1], )                                                         \
             }                                                                                       \
             {                                                                                       \
-                P1(3, gg[1], gg[0], ta_next, Q4 * 4)                                                \
+                P1(3, gg[1], gg[0], ta_next, 0, 0)                                                  \
                 RF_LOAD_WINDOW(wa_next)                                                             \
-                RF_G4_PART2(tq[1], gg[0], RF_COMMA_W)                                               \
+                RF_G4_PART2(tp[0], gg[0], RF_COMMA_W)                                               \
             }                                                                                       \
         }                                                                                           \
         ta = ta_next;                                                                               \
@@ -818,6 +831,17 @@ __device__ __forceinline__ void jbf_tap_loop_grey4(uint32_t lut_lane_addr, uint3
 #undef RF_G4_PART1
 #undef RF_G4_PART2
 #undef RF_TEXEL_OFF4
+#undef RF_TQ
+#undef RF_G4_READ
+#undef RF_G4_READ_0
+#undef RF_G4_READ_1
+#undef RF_G4_READ_2
+#undef RF_G4_READ_3
+#undef RF_G4_TNOUT
+#undef RF_G4_TNOUT_0
+#undef RF_G4_TNOUT_1
+#undef RF_G4_TNOUT_2
+#undef RF_G4_TNOUT_3
 }
 
 // Hand-scheduled tap loop for colour tiles with 6-byte texels (main plane {B,G,R joint, B src},
