@@ -4,9 +4,11 @@
 The reference handles one image per invocation (/root/reference/filter_reflectance.py:76-96,
 /root/reference/decompose_with_trained_CNN.py:98-130).  Every image is independent, so a list of
 files shards embarrassingly: each rank (torchrun sets RANK/WORLD_SIZE/LOCAL_RANK) takes a
-contiguous slice of the sorted file list, groups its images by size, pushes each group through
-the device-resident batch operators and writes the same output files the single-image tools
-would write.  No collective is involved.
+contiguous slice of the sorted file list and works through it in steps of 16 files as a pipeline
+- a thread pool decodes the next step and encodes the previous one while the device filters the
+current one - grouping the images of a step by size, pushing each group through the
+device-resident batch operators and writing the same output files the single-image tools would
+write.  No collective is involved.
 
     python -m reflectance_filtering_amd.batch filter --filter_type=bilateral --sigma_color=20 \
         --sigma_spatial=22 --inputs 'out/*-r.png' --guidance 'photos/{stem}.png' --path_out out
@@ -33,18 +35,41 @@ from . import image_utils as iu
 from . import sharding
 
 MAX_BATCH_BYTES = 2 << 30  # per group of equal-size images kept on the device at once
+STEP_FILES = 16            # files per pipeline step (decode k+1 | device k | encode k-1)
 IO_THREADS = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity")
                         else (os.cpu_count() or 1)))
 
 
-def _parallel(fn, items):
-    """Image decode / encode spends its time in zlib with the GIL released: a small thread pool
-    keeps the host side from serialising a batch (results in input order)."""
+def pipeline(items, load, compute, step=None):
+    """Three-stage pipeline over `items` in steps of `step` files: while the device works on step
+    k (in the calling thread: `compute(list of load() results)` returns a list of
+    (file name, array) pairs to write), the thread pool decodes step k+1 and encodes what step k-1
+    produced.  Image decode / encode spend their time in zlib with the GIL released and the device
+    calls release it too, so the three stages overlap; at most two decoded steps and two steps of
+    pending writes are alive at a time.  Returns the names written, in order."""
+    step = step or STEP_FILES
     items = list(items)
-    if len(items) < 2 or IO_THREADS < 2:
-        return [fn(it) for it in items]
+    steps = [items[i:i + step] for i in range(0, len(items), step)]
+    written = []
+    if not steps:
+        return written
     with ThreadPoolExecutor(max_workers=IO_THREADS) as pool:
-        return list(pool.map(fn, items))
+        loads = [pool.submit(load, it) for it in steps[0]]
+        pending = []                       # write futures of the previous steps, oldest first
+        for k, _ in enumerate(steps):
+            nxt = [pool.submit(load, it) for it in steps[k + 1]] if k + 1 < len(steps) else []
+            loaded = [f.result() for f in loads]
+            jobs = compute(loaded)
+            while len(pending) > 1:        # writes of step k-2 must be done before step k's start
+                for f in pending.pop(0):
+                    f.result()
+            pending.append([pool.submit(iu.imwrite, name, arr) for name, arr in jobs])
+            written.extend(name for name, _ in jobs)
+            loads = nxt
+        for futs in pending:
+            for f in futs:
+                f.result()
+    return written
 
 
 def expand_inputs(patterns):
@@ -110,45 +135,48 @@ def filter_files(filter_type, inputs, guidance_pattern, sigma_color, sigma_spati
     import torch
     fr._check_params(filter_type, sigma_color, sigma_spatial)
     mine = my_slice(inputs, rank, world)
-    loaded = _parallel(lambda f: (f, iu.imread(f), iu.imread(guidance_for(f, guidance_pattern))),
-                       mine)
-    for f, img, gui in loaded:
+
+    def load(f):
+        img, gui = iu.imread(f), iu.imread(guidance_for(f, guidance_pattern))
         if img.shape[:2] != gui.shape[:2]:
             raise ValueError("input {} and its guidance differ in size".format(f))
-    written = []
-    for group in group_by_shape(loaded, lambda t: t[1].shape):
-        imgs = np.stack([t[1] for t in group])
-        guis = np.stack([t[2] for t in group])
-        # A grey PNG comes back from imread as three equal channels (the CNN's `-r.png` always
-        # does).  The channels never mix in either filter, so such a group is filtered as one
-        # channel - a third of the transfers and of the guided filter's scratch, all tile shapes
-        # of the bilateral kernel - and replicated afterwards: identical bytes.
-        grey_src = _is_grey(imgs)
-        if grey_src:
-            imgs = imgs[..., :1]
-        images = torch.from_numpy(np.ascontiguousarray(imgs)).cuda()
-        if filter_type == "bilateral" and grey_src and _is_grey(guis):
-            joints = torch.from_numpy(np.ascontiguousarray(guis[..., :1])).cuda()
-            out = images
-            for _ in range(iterations):
-                out = ops.joint_bilateral_u8(joints, out, -1, sigma_color, sigma_spatial,
-                                             grey_as_bgr=True)
-        else:
-            joints = torch.from_numpy(guis).cuda()
-            out = fr.apply_filter_batch(filter_type, images, joints, sigma_color, sigma_spatial,
-                                        iterations=iterations)
-        out = out.cpu().numpy()
-        if grey_src:
-            out = np.repeat(out, 3, axis=3)
+        return f, img, gui
+
+    def compute(loaded):
         jobs = []
-        for (f, _, _), res in zip(group, out):
-            name = f
-            for _ in range(iterations):  # the chained CLI runs append the suffix once per pass
-                name = fr.output_filename(name, path_out, filter_type, sigma_color, sigma_spatial)
-            jobs.append((name, res))
-            written.append(name)
-        _parallel(lambda job: iu.imwrite(*job), jobs)
-    return written
+        for group in group_by_shape(loaded, lambda t: t[1].shape):
+            imgs = np.stack([t[1] for t in group])
+            guis = np.stack([t[2] for t in group])
+            # A grey PNG comes back from imread as three equal channels (the CNN's `-r.png` always
+            # does).  The channels never mix in either filter, so such a group is filtered as one
+            # channel - a third of the transfers and of the guided filter's scratch, all tile
+            # shapes of the bilateral kernel - and replicated afterwards: identical bytes.
+            grey_src = _is_grey(imgs)
+            if grey_src:
+                imgs = imgs[..., :1]
+            images = torch.from_numpy(np.ascontiguousarray(imgs)).cuda()
+            if filter_type == "bilateral" and grey_src and _is_grey(guis):
+                joints = torch.from_numpy(np.ascontiguousarray(guis[..., :1])).cuda()
+                out = images
+                for _ in range(iterations):
+                    out = ops.joint_bilateral_u8(joints, out, -1, sigma_color, sigma_spatial,
+                                                 grey_as_bgr=True)
+            else:
+                joints = torch.from_numpy(guis).cuda()
+                out = fr.apply_filter_batch(filter_type, images, joints, sigma_color,
+                                            sigma_spatial, iterations=iterations)
+            out = out.cpu().numpy()
+            if grey_src:
+                out = np.repeat(out, 3, axis=3)
+            for (f, _, _), res in zip(group, out):
+                name = f
+                for _ in range(iterations):  # the chained CLI runs append the suffix once per pass
+                    name = fr.output_filename(name, path_out, filter_type, sigma_color,
+                                              sigma_spatial)
+                jobs.append((name, res))
+        return jobs
+
+    return pipeline(mine, load, compute)
 
 
 def decompose_files(inputs, path_out, rank=None, world=None):
@@ -158,21 +186,24 @@ def decompose_files(inputs, path_out, rank=None, world=None):
     import torch
     from . import decompose_with_trained_CNN as dc
     mine = my_slice(inputs, rank, world)
-    loaded = _parallel(lambda f: (f, iu.imread(f)), mine)
-    written = []
-    for group in group_by_shape(loaded, lambda t: t[1].shape):
-        images = torch.from_numpy(np.stack([t[1] for t in group])).cuda()
-        _, r8, refl, shad = dc.decompose_batch(images)
-        r8, refl, shad = r8.cpu().numpy(), refl.cpu().numpy(), shad.cpu().numpy()
+    firsts = []
+
+    def compute(loaded):
         jobs = []
-        for i, (f, _) in enumerate(group):
-            base = os.path.splitext(os.path.basename(f))[0]
-            jobs.append((os.path.join(path_out, base + "-r.png"), r8[i]))
-            jobs.append((os.path.join(path_out, base + "-r_colorized.png"), refl[i]))
-            jobs.append((os.path.join(path_out, base + "-s_colorized.png"), shad[i]))
-            written.append(os.path.join(path_out, base + "-r.png"))
-        _parallel(lambda job: iu.imwrite(*job), jobs)
-    return written
+        for group in group_by_shape(loaded, lambda t: t[1].shape):
+            images = torch.from_numpy(np.stack([t[1] for t in group])).cuda()
+            _, r8, refl, shad = dc.decompose_batch(images)
+            r8, refl, shad = r8.cpu().numpy(), refl.cpu().numpy(), shad.cpu().numpy()
+            for i, (f, _) in enumerate(group):
+                base = os.path.splitext(os.path.basename(f))[0]
+                jobs.append((os.path.join(path_out, base + "-r.png"), r8[i]))
+                jobs.append((os.path.join(path_out, base + "-r_colorized.png"), refl[i]))
+                jobs.append((os.path.join(path_out, base + "-s_colorized.png"), shad[i]))
+                firsts.append(os.path.join(path_out, base + "-r.png"))
+        return jobs
+
+    pipeline(mine, lambda f: (f, iu.imread(f)), compute)
+    return firsts
 
 
 def build_parser():

@@ -274,3 +274,36 @@ def test_imread_16bit_png_keeps_the_high_byte_whatever_the_values(tmp_path):
         got = iu.imread(str(f))
         assert got.shape == (3, 4, 3) and got.dtype == np.uint8
         assert np.array_equal(got[:, :, 0], (vals >> 8).astype(np.uint8))
+
+
+def test_batch_pipeline_orders_overlaps_and_propagates_errors(tmp_path):
+    """batch.pipeline: results are written in input order whatever the step size, every file is
+    loaded exactly once, and an exception of a stage surfaces in the caller."""
+    import threading
+    from reflectance_filtering_amd import batch, image_utils as iu
+    items = list(range(11))
+    seen, lock = [], threading.Lock()
+
+    def load(i):
+        with lock:
+            seen.append(i)
+        return i, np.full((4, 5, 3), i, np.uint8)
+
+    def compute(loaded):
+        return [(str(tmp_path / ("o%02d.png" % i)), arr + 1) for i, arr in loaded]
+
+    for step in (1, 4, 64):
+        seen.clear()
+        names = batch.pipeline(items, load, compute, step=step)
+        assert names == [str(tmp_path / ("o%02d.png" % i)) for i in items]
+        assert sorted(seen) == items
+        for i, name in zip(items, names):
+            assert int(iu.imread(name)[0, 0, 0]) == i + 1
+    assert batch.pipeline([], load, compute) == []
+
+    def bad(loaded):
+        raise RuntimeError("device stage failed")
+    with pytest.raises(RuntimeError, match="device stage failed"):
+        batch.pipeline(items, load, bad, step=3)
+    with pytest.raises(ZeroDivisionError):
+        batch.pipeline(items, lambda i: 1 // 0, compute, step=3)
