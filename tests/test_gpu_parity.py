@@ -661,10 +661,14 @@ def test_two_streams_do_not_share_scratch(env):
     from tests import synth
     rf, co, torch = env
     h, w = 700, 900
-    ga = torch.from_numpy(synth.flat_guide_u8(h, w, seed=1, cells=30)[None]).cuda()
-    gb = torch.from_numpy(synth.scene_u8(h, w, seed=2)[None]).cuda()
-    sa = torch.from_numpy(synth.scene_u8(h, w, seed=3)[None]).cuda()
-    sb = torch.from_numpy(synth.reflectance_like_u8(h, w, seed=4)[None]).cuda()
+    # two images per call: each call forks the library's side stream for its second image, so
+    # the two callers also share that stream
+    ga = torch.from_numpy(np.stack([synth.flat_guide_u8(h, w, seed=1, cells=30),
+                                    synth.flat_guide_u8(h, w, seed=11, cells=20)])).cuda()
+    gb = torch.from_numpy(np.stack([synth.scene_u8(h, w, seed=2), synth.scene_u8(h, w, seed=12)])).cuda()
+    sa = torch.from_numpy(np.stack([synth.scene_u8(h, w, seed=3), synth.scene_u8(h, w, seed=13)])).cuda()
+    sb = torch.from_numpy(np.stack([synth.reflectance_like_u8(h, w, seed=4),
+                                    synth.reflectance_like_u8(h, w, seed=14)])).cuda()
     want_a = rf.ops.guided_filter_u8(ga, sa, 45, 3.0, iterations=2)
     want_b = rf.ops.guided_filter_u8(gb, sb, 45, 3.0, iterations=2)
     wts = rf.weights.load_weights()
