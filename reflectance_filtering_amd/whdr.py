@@ -8,8 +8,9 @@ Mirrors the evaluation arithmetic of the reference's training layer
     comparisons[k] = (x1, y1, x2, y2, darker, weight)   x, y normalised to [0,1);
                      darker: 0 = 'E' (about equal), 1 = point 1 darker, 2 = point 2 darker
 
-`whdr` is the per-image host form (same numpy operations as the reference, so it follows the
-installed numpy's scalar promotion rules exactly as the reference would under it);
+`whdr` is the per-image host form: one fancy-indexed gather and vectorised decisions over all
+judgements of an image, with the dtype promotions the reference's scalar loop would go through
+under the installed numpy (pinned on the reference's own values, tests/golden/whdr.npz);
 `whdr_batch` evaluates many device-resident predictions in one launch (rf_whdr_f32).
 """
 from __future__ import division, print_function
@@ -39,42 +40,62 @@ def load_judgements(json_path):
 
 
 def to_pixels(comparisons, height, width):
-    """Normalised -> pixel coordinates by truncation, in the array's own dtype
-    (whdr_layer.py:239-250)."""
-    res = np.array(comparisons, copy=True)
-    res[:, [0, 2]] = (res[:, [0, 2]] * width).astype(int)
-    res[:, [1, 3]] = (res[:, [1, 3]] * height).astype(int)
-    return res
+    """Normalised -> pixel coordinates (x * width, y * height, truncated toward zero), stored
+    back in the array's own dtype; the judgement and weight columns are untouched
+    (contract: whdr_layer.py:239-250)."""
+    px = np.array(comparisons, copy=True)
+    size = np.array([width, height, width, height])
+    px[:, :4] = np.trunc(px[:, :4] * size)
+    return px
 
 
-def _lightness(r):
-    if len(r) == 3:
-        return max(EPS, np.mean(r))
-    if len(r) == 1:
-        return max(EPS, r)
-    raise Exception("Expecting 1 or 3 channels to compute lightness!")
+def _point_lightness(reflectance, ys, xs):
+    """Lightness of the pixels (ys[i], xs[i]) of a [c,h,w] image, one gather for all points:
+    the channel mean (3 channels, in the image's dtype like np.mean of one pixel) or the value
+    itself (1 channel), floored at EPS.  A NaN fails `> EPS` and becomes EPS, as it does through
+    Python's max() in the reference (whdr_layer.py:180-196)."""
+    channels = reflectance.shape[0]
+    if channels not in (1, 3):
+        raise Exception("Expecting 1 or 3 channels to compute lightness!")
+    picked = reflectance[:, ys, xs]                       # [c, n]
+    value = picked[0] if channels == 1 else picked.mean(axis=0)
+    return np.where(value > EPS, value, EPS)
 
 
 def whdr(reflectance, comparisons, delta=0.1):
-    """WHDR of one [c,h,w] reflectance image; `comparisons` in pixel coordinates
-    (whdr_layer.py:253-287).  No comparisons -> 0.0."""
-    error_sum = 0.0
-    weight_sum = 0.0
-    for c in range(comparisons.shape[0]):
-        x1, y1, x2, y2, darker = comparisons[c, :5].astype(int)
-        weight = comparisons[c, 5]
-        l1 = _lightness(reflectance[:, y1, x1])
-        l2 = _lightness(reflectance[:, y2, x2])
-        if l2 / l1 > 1 + delta:
-            alg_darker = 1
-        elif l1 / l2 > 1 + delta:
-            alg_darker = 2
-        else:
-            alg_darker = 0
-        if darker != alg_darker:
-            error_sum += weight
-        weight_sum += weight
-    return error_sum / weight_sum if weight_sum else 0.0
+    """WHDR of one [c,h,w] reflectance image against judgements in pixel coordinates: the
+    weight of the judgements the image disagrees with over the weight of all of them
+    (arithmetic contract: whdr_layer.py:253-287).  No judgements -> 0.0.
+
+    All judgements are decided at once: the image says "point 1 darker" (1) when l2/l1 exceeds
+    1 + delta, else "point 2 darker" (2) when l1/l2 does, else "about equal" (0).  The two
+    weight totals are running sums in judgement order (np.cumsum adds sequentially) in the
+    dtype `0.0 + weight` has under the installed numpy, and the threshold is compared in the
+    dtype `lightness ratio > python float` is compared in under it - the same promotions the
+    reference's scalar loop goes through."""
+    reflectance = np.asarray(reflectance)
+    judgements = np.asarray(comparisons)
+    if judgements.shape[0] == 0:
+        if reflectance.shape[0] not in (1, 3):
+            raise Exception("Expecting 1 or 3 channels to compute lightness!")
+        return 0.0
+    pts = judgements[:, :5].astype(int)
+    first = _point_lightness(reflectance, pts[:, 1], pts[:, 0])
+    second = _point_lightness(reflectance, pts[:, 3], pts[:, 2])
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        up, down = second / first, first / second
+    # scalar-vs-python-float promotion of the installed numpy (float32 under NumPy >= 2)
+    cmp_t = (first.dtype.type(1) * 1.5).dtype
+    limit = cmp_t.type(1 + delta)
+    verdict = np.where(up.astype(cmp_t) > limit, 1, np.where(down.astype(cmp_t) > limit, 2, 0))
+    weights = judgements[:, 5]
+    acc_t = (0.0 + weights.dtype.type(0)).dtype
+    weights = weights.astype(acc_t)
+    total = np.cumsum(weights)[-1]
+    if not total:
+        return 0.0
+    wrong = np.cumsum(np.where(verdict != pts[:, 4], weights, acc_t.type(0)))[-1]
+    return wrong / total
 
 
 def whdr_batch(reflectances, comparisons_px, delta=0.1):

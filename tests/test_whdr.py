@@ -26,6 +26,41 @@ def test_host_whdr_matches_reference_values():
         W.whdr(np.ones((2, 4, 4), np.float32), np.array([[0, 0, 1, 1, 1, 1.0]]))
 
 
+def _whdr_by_definition(refl, px, delta):
+    """[Bell 2014] spelled out one judgement at a time (float32 image, float64 judgements)."""
+    wrong = total = 0.0
+    for x1, y1, x2, y2, darker, weight in px:
+        l = []
+        for x, y in ((x1, y1), (x2, y2)):
+            v = refl[:, int(y), int(x)]
+            v = v[0] if len(v) == 1 else (v[0] + v[1] + v[2]) / np.float32(3)
+            l.append(v if v > W.EPS else W.EPS)
+        limit = np.float32(1 + delta)
+        says = 1 if l[1] / l[0] > limit else (2 if l[0] / l[1] > limit else 0)
+        wrong += weight * (says != int(darker))
+        total += weight
+    return wrong / total if total else 0.0
+
+
+def test_host_whdr_edge_cases_match_the_definition():
+    rng = np.random.default_rng(3)
+    for trial in range(40):
+        c = (1, 3)[trial % 2]
+        refl = (rng.random((c, 9, 13)) ** 3).astype(np.float32)
+        refl[:, 2, 3] = 0                         # floored at EPS
+        refl[:, 4, 5] = np.nan                    # NaN lightness -> EPS
+        k = (0, 1, 50)[trial % 3]
+        comp = np.zeros((k, 6))
+        comp[:, :4] = rng.random((k, 4)) * 0.999
+        comp[:, 4] = rng.integers(0, 3, k)
+        comp[:, 5] = rng.random(k) if trial % 5 else 0.0   # all-zero weights -> 0.0
+        px = W.to_pixels(comp, 9, 13)
+        if k:
+            px[0, :4] = (3, 2, 5, 4)
+        with np.errstate(all="ignore"):
+            assert W.whdr(refl, px, 0.1) == _whdr_by_definition(refl, px, 0.1), trial
+
+
 def test_load_judgements_reads_iiw_json(tmp_path):
     doc = {"intrinsic_points": [{"id": 7, "x": 0.25, "y": 0.5, "opaque": True},
                                 {"id": 9, "x": 0.75, "y": 0.125, "opaque": True},
