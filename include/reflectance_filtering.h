@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define RF_VERSION 100 /* 0.1.0 */
+#define RF_VERSION 101 /* 0.1.1 */
 
 /* return codes */
 #define RF_OK 0
@@ -51,7 +51,9 @@ extern "C" {
 
 int rf_version(void);
 const char *rf_last_error(void);
-/* Frees the per-device parameter tables (colour LUTs, tap tables). */
+/* Frees what the library holds: the per-device parameter tables (colour LUTs, tap tables), the
+   packed-weight slots of rf_cnn_reflectance_u8 and the guided filter's side streams.  Call it with
+   no library work in flight. */
 int rf_shutdown(void);
 
 /*
@@ -84,6 +86,8 @@ int rf_jbf_u8(const uint8_t *joint, const uint8_t *src, uint8_t *dst, int n, int
  *   stream: all work is ordered after what `stream` holds at the call and before what is
  *   enqueued on it afterwards; inside, half of a batch may run on a side stream of the library
  *   that is forked from and joined back into `stream` with events (graph capture keeps working).
+ *   Side streams are per caller stream (at most 16 are kept), so concurrent callers on different
+ *   streams - eager or capturing - never meet on one.
  */
 size_t rf_gf_workspace_bytes(int n, int h, int w, int guide_cn, int src_cn, int radius);
 int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, int n, int h, int w,
@@ -106,6 +110,21 @@ int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, int n, int 
 #define RF_CNN_NPARAMS 4513
 int rf_cnn_reflectance_u8(const uint8_t *bgr, float *r_out, uint8_t *r_u8_out, int n, int h, int w,
                           const float *weights, const float *srgb_lut, void *stream);
+/*
+ * The same forward pass split the way pycaffe splits it: rf_cnn_pack_weights is the net-load step
+ * (caffe.Net(prototxt, TEST, weights=...), /root/reference/decompose_with_trained_CNN.py:104-106),
+ * done once per set of weights; rf_cnn_reflectance_packed_u8 is forward() on a loaded net
+ * (:86-92).  The library keeps no state for this pair, so it can be captured into a HIP graph and
+ * used from any number of streams.  rf_cnn_reflectance_u8 above is pack + forward in one call,
+ * with the packed copy in a small library-owned table keyed by (device, stream); its FIRST call on
+ * a stream allocates and is therefore refused (RF_E_UNSUPPORTED) while that stream is captured.
+ *   weights  4513 float32 on the device, layout as above
+ *   packed   4513 float32 on the device, caller-owned: the weights in the order the kernel streams
+ *            them (an opaque permutation; valid for this library version)
+ */
+int rf_cnn_pack_weights(const float *weights, float *packed, void *stream);
+int rf_cnn_reflectance_packed_u8(const uint8_t *bgr, float *r_out, uint8_t *r_u8_out, int n, int h,
+                                 int w, const float *packed, const float *srgb_lut, void *stream);
 
 /*
  * Colourised reflectance and shading PNG bytes of decompose_image.

@@ -21,7 +21,8 @@ JBF_GREY_AS_BGR = 4
 CNN_NPARAMS = 4513
 
 EXPORTS = ("rf_version", "rf_last_error", "rf_shutdown", "rf_jbf_u8", "rf_gf_workspace_bytes",
-           "rf_gf_u8", "rf_cnn_reflectance_u8", "rf_colorize_workspace_bytes",
+           "rf_gf_u8", "rf_cnn_reflectance_u8", "rf_cnn_pack_weights",
+           "rf_cnn_reflectance_packed_u8", "rf_colorize_workspace_bytes",
            "rf_colorize_srgb_u8", "rf_whdr_f32", "rf_jbf_f32_workspace_bytes", "rf_jbf_f32",
            "rf_gf_f32_workspace_bytes", "rf_gf_f32")
 
@@ -66,6 +67,10 @@ def load_library():
         lib.rf_gf_u8.restype = ci
         lib.rf_cnn_reflectance_u8.argtypes = [vp, vp, vp, ci, ci, ci, vp, vp, vp]
         lib.rf_cnn_reflectance_u8.restype = ci
+        lib.rf_cnn_pack_weights.argtypes = [vp, vp, vp]
+        lib.rf_cnn_pack_weights.restype = ci
+        lib.rf_cnn_reflectance_packed_u8.argtypes = [vp, vp, vp, ci, ci, ci, vp, vp, vp]
+        lib.rf_cnn_reflectance_packed_u8.restype = ci
         u64 = ctypes.c_ulonglong
         lib.rf_colorize_workspace_bytes.argtypes = [ci]
         lib.rf_colorize_workspace_bytes.restype = sz

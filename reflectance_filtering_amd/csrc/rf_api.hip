@@ -10,6 +10,7 @@ namespace rf {
 
 void jbf_shutdown();
 void cnn_shutdown();
+void gf_shutdown();
 
 char *last_error_buf()
 {
@@ -55,5 +56,6 @@ extern "C" int rf_shutdown(void)
 {
     rf::jbf_shutdown();
     rf::cnn_shutdown();
+    rf::gf_shutdown();
     return RF_OK;
 }

@@ -457,31 +457,113 @@ __global__ __launch_bounds__(kCnnThreads) void cnn_reflectance_regs_kernel(
 #undef RF_PKMUL_P0
 #undef RF_PKMUL_P1
 
-// One packed copy of the weights per (device, stream): a call re-packs the caller's weights on
-// its own stream (18 tiny workgroups; the weights may have changed since the last call), so calls
-// on different streams of one device never share a buffer and calls on one stream are ordered.
+// rf_cnn_reflectance_u8 (raw weights) keeps one packed copy per (device, stream): a call re-packs
+// the caller's weights on its own stream (18 tiny workgroups; the weights may have changed since
+// the last call), so calls on different streams never share a buffer and calls on one stream are
+// ordered.  The table is bounded (kMaxSlots): when it is full the least recently used slot whose
+// stream has drained is recycled (a stream that no longer exists counts as drained; if every slot
+// is busy the oldest one's stream is waited for).  Nothing is allocated or recycled while the
+// caller's stream is being captured: a capture needs either a slot made by an earlier call on
+// that stream or the stateless pair rf_cnn_pack_weights + rf_cnn_reflectance_packed_u8.
 struct PackedSlot {
     int device;
     hipStream_t stream;
     float *buf;
+    unsigned long long used;  // tick of the last call
 };
+constexpr size_t kMaxSlots = 16;
 std::mutex g_cnn_mu;
 std::vector<PackedSlot> g_packed;
+unsigned long long g_tick = 0;
 
 int packed_buffer(hipStream_t stream, float **out)
 {
     int dev = 0;
     RF_HIP_CHECK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(g_cnn_mu);
-    for (const PackedSlot &s : g_packed)
+    for (PackedSlot &s : g_packed)
         if (s.device == dev && s.stream == stream) {
+            s.used = ++g_tick;
             *out = s.buf;
             return RF_OK;
         }
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess)
+        (void)hipGetLastError();
+    if (cap != hipStreamCaptureStatusNone)
+        return fail(RF_E_UNSUPPORTED,
+                    "rf_cnn_reflectance_u8: first call on a stream that is being captured (it would "
+                    "allocate); call it once on this stream before the capture, or capture "
+                    "rf_cnn_reflectance_packed_u8 on weights packed beforehand");
+    if (g_packed.size() >= kMaxSlots) {
+        // recycle: least recently used slot whose stream has nothing pending
+        size_t pick = g_packed.size(), oldest = 0;
+        for (size_t i = 0; i < g_packed.size(); i++) {
+            if (g_packed[i].used < g_packed[oldest].used)
+                oldest = i;
+            const hipError_t q = hipStreamQuery(g_packed[i].stream);
+            if (q == hipErrorNotReady)
+                continue;
+            if (q != hipSuccess)
+                (void)hipGetLastError();  // the stream is gone: nothing of it can be in flight
+            if (pick == g_packed.size() || g_packed[i].used < g_packed[pick].used)
+                pick = i;
+        }
+        if (pick == g_packed.size()) {
+            pick = oldest;
+            if (hipStreamSynchronize(g_packed[pick].stream) != hipSuccess)
+                (void)hipGetLastError();
+        }
+        PackedSlot &s = g_packed[pick];
+        if (s.device != dev) {
+            (void)hipFree(s.buf);
+            s.buf = nullptr;
+            float *buf = nullptr;
+            const hipError_t e = hipMalloc(&buf, sizeof(float) * kPackedFloats);
+            if (e != hipSuccess) {
+                g_packed.erase(g_packed.begin() + (long)pick);
+                return fail(RF_E_HIP, "hipMalloc of the packed weights failed: %s",
+                            hipGetErrorString(e));
+            }
+            s.buf = buf;
+        }
+        s.device = dev;
+        s.stream = stream;
+        s.used = ++g_tick;
+        *out = s.buf;
+        return RF_OK;
+    }
     float *buf = nullptr;
     RF_HIP_CHECK(hipMalloc(&buf, sizeof(float) * kPackedFloats));
-    g_packed.push_back({dev, stream, buf});
+    g_packed.push_back({dev, stream, buf, ++g_tick});
     *out = buf;
+    return RF_OK;
+}
+
+int launch_forward(const uint8_t *bgr, float *r_out, uint8_t *r_u8_out, int n, int h, int w,
+                   const float *packed, const float *srgb_lut, hipStream_t stream)
+{
+    const size_t npix = (size_t)n * h * w;
+    size_t blocks = ((npix + 1) / 2 + kCnnThreads - 1) / kCnnThreads;
+    if (blocks > 256 * 20)
+        blocks = 256 * 20;
+    if (debug_get(kDbgCnnLdsColumns))  // cross-check: the LDS-column form of round 1
+        hipLaunchKernelGGL(cnn_reflectance_kernel, dim3((unsigned)blocks), dim3(kCnnThreads), 0,
+                           stream, bgr, r_out, r_u8_out, npix, packed, srgb_lut);
+    else
+        hipLaunchKernelGGL(cnn_reflectance_regs_kernel, dim3((unsigned)blocks), dim3(kCnnThreads),
+                           0, stream, bgr, r_out, r_u8_out, npix, packed, srgb_lut);
+    RF_HIP_CHECK(hipGetLastError());
+    return RF_OK;
+}
+
+int check_forward_args(const char *who, const void *bgr, const void *weights, const void *srgb_lut,
+                       const void *r_out, const void *r_u8_out, int n, int h, int w)
+{
+    if (!bgr || !weights || !srgb_lut || (!r_out && !r_u8_out))
+        return fail(RF_E_BADARG, "%s: NULL pointer", who);
+    if (n < 0 || h <= 0 || w <= 0)
+        return fail(RF_E_BADARG, "%s: bad size n=%d h=%d w=%d", who, n, h, w);
     return RF_OK;
 }
 
@@ -497,38 +579,53 @@ void cnn_shutdown()
 
 }  // namespace rf
 
+extern "C" int rf_cnn_pack_weights(const float *weights, float *packed, void *stream_)
+{
+    using namespace rf;
+    static_assert(kPackedFloats == RF_CNN_NPARAMS, "packed layout is a permutation");
+    if (!weights || !packed)
+        return fail(RF_E_BADARG, "rf_cnn_pack_weights: NULL pointer");
+    if (ranges_overlap(weights, sizeof(float) * RF_CNN_NPARAMS, packed,
+                       sizeof(float) * RF_CNN_NPARAMS))
+        return fail(RF_E_BADARG, "rf_cnn_pack_weights: packed must not overlap weights");
+    hipLaunchKernelGGL(cnn_pack_weights_kernel, dim3((RF_CNN_NPARAMS + 255) / 256), dim3(256), 0,
+                       (hipStream_t)stream_, weights, packed);
+    RF_HIP_CHECK(hipGetLastError());
+    return RF_OK;
+}
+
+extern "C" int rf_cnn_reflectance_packed_u8(const uint8_t *bgr, float *r_out, uint8_t *r_u8_out,
+                                            int n, int h, int w, const float *packed,
+                                            const float *srgb_lut, void *stream_)
+{
+    using namespace rf;
+    if (n == 0)  // an empty batch is valid whatever the (possibly NULL) pointers are
+        return RF_OK;
+    const int rc = check_forward_args("rf_cnn_reflectance_packed_u8", bgr, packed, srgb_lut, r_out,
+                                      r_u8_out, n, h, w);
+    if (rc != RF_OK)
+        return rc;
+    return launch_forward(bgr, r_out, r_u8_out, n, h, w, packed, srgb_lut, (hipStream_t)stream_);
+}
+
 extern "C" int rf_cnn_reflectance_u8(const uint8_t *bgr, float *r_out, uint8_t *r_u8_out, int n,
                                      int h, int w, const float *weights, const float *srgb_lut,
                                      void *stream_)
 {
     using namespace rf;
-    if (n == 0)  // an empty batch is valid whatever the (possibly NULL) pointers are
-        return RF_OK;
-    static_assert(kPackedFloats == RF_CNN_NPARAMS, "packed layout is a permutation");
-    if (!bgr || !weights || !srgb_lut || (!r_out && !r_u8_out))
-        return fail(RF_E_BADARG, "rf_cnn_reflectance_u8: NULL pointer");
-    if (n < 0 || h <= 0 || w <= 0)
-        return fail(RF_E_BADARG, "rf_cnn_reflectance_u8: bad size n=%d h=%d w=%d", n, h, w);
     if (n == 0)
         return RF_OK;
+    int rc = check_forward_args("rf_cnn_reflectance_u8", bgr, weights, srgb_lut, r_out, r_u8_out,
+                                n, h, w);
+    if (rc != RF_OK)
+        return rc;
     hipStream_t stream = (hipStream_t)stream_;
     float *packed = nullptr;
-    int rc = packed_buffer(stream, &packed);
+    rc = packed_buffer(stream, &packed);
     if (rc != RF_OK)
         return rc;
     // (the packed copy is rebuilt on the caller's stream every call: the weights may have changed)
     hipLaunchKernelGGL(cnn_pack_weights_kernel, dim3((RF_CNN_NPARAMS + 255) / 256), dim3(256), 0,
                        stream, weights, packed);
-    const size_t npix = (size_t)n * h * w;
-    size_t blocks = ((npix + 1) / 2 + kCnnThreads - 1) / kCnnThreads;
-    if (blocks > 256 * 20)
-        blocks = 256 * 20;
-    if (debug_get(kDbgCnnLdsColumns))  // cross-check: the LDS-column form of round 1
-        hipLaunchKernelGGL(cnn_reflectance_kernel, dim3((unsigned)blocks), dim3(kCnnThreads), 0,
-                           stream, bgr, r_out, r_u8_out, npix, packed, srgb_lut);
-    else
-        hipLaunchKernelGGL(cnn_reflectance_regs_kernel, dim3((unsigned)blocks), dim3(kCnnThreads),
-                           0, stream, bgr, r_out, r_u8_out, npix, packed, srgb_lut);
-    RF_HIP_CHECK(hipGetLastError());
-    return RF_OK;
+    return launch_forward(bgr, r_out, r_u8_out, n, h, w, packed, srgb_lut, stream);
 }

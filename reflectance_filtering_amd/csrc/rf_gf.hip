@@ -1029,19 +1029,83 @@ int gf_f32_chunk(const float *guide, const float *src, float *dst, int m, int h,
 
 }  // namespace
 
-// The library's side stream of the current device (created on first use, lives until exit).
-hipStream_t gf_side_stream()
+// Side streams for the second half of a batch, one per CALLER stream (so two callers never meet
+// on one side stream, and a caller that captures its stream into a graph pulls only its own side
+// stream into that capture).  The table is bounded: when it is full the least recently used entry
+// whose side stream is idle is destroyed and replaced; if none is idle, or the caller's stream
+// belongs to another device than the current one, the call runs on the caller's stream alone
+// (nullptr).  rf_shutdown() destroys them all.
+namespace {
+struct SideStream {
+    hipStream_t caller, side;
+    int device;
+    unsigned long long used;
+};
+constexpr size_t kMaxSideStreams = 16;
+std::mutex g_side_mu;
+SideStream g_side[kMaxSideStreams];
+size_t g_side_n = 0;
+unsigned long long g_side_tick = 0;
+}  // namespace
+
+hipStream_t gf_side_stream(hipStream_t caller)
 {
-    static std::mutex mu;
-    static hipStream_t streams[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+    int dev = 0, sdev = 0;
+    if (hipGetDevice(&dev) != hipSuccess)
         return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    if (streams[dev] == nullptr &&
-        hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking) != hipSuccess)
-        streams[dev] = nullptr;
-    return streams[dev];
+    if (caller != nullptr) {
+        if (hipStreamGetDevice(caller, &sdev) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        if (sdev != dev)
+            return nullptr;
+    }
+    std::lock_guard<std::mutex> lock(g_side_mu);
+    for (size_t i = 0; i < g_side_n; i++)
+        if (g_side[i].caller == caller && g_side[i].device == dev) {
+            g_side[i].used = ++g_side_tick;
+            return g_side[i].side;
+        }
+    size_t slot = g_side_n;
+    if (g_side_n == kMaxSideStreams) {
+        slot = kMaxSideStreams;
+        for (size_t i = 0; i < g_side_n; i++) {
+            if (slot != kMaxSideStreams && g_side[i].used > g_side[slot].used)
+                continue;
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(g_side[i].side, &cap) != hipSuccess ||
+                cap != hipStreamCaptureStatusNone || hipStreamQuery(g_side[i].side) != hipSuccess) {
+                (void)hipGetLastError();
+                continue;
+            }
+            slot = i;
+        }
+        if (slot == kMaxSideStreams)
+            return nullptr;
+        (void)hipStreamDestroy(g_side[slot].side);
+    }
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        if (slot != g_side_n) {  // the recycled entry is gone: close the gap
+            g_side[slot] = g_side[g_side_n - 1];
+            g_side_n--;
+        }
+        return nullptr;
+    }
+    g_side[slot] = {caller, st, dev, ++g_side_tick};
+    if (slot == g_side_n)
+        g_side_n++;
+    return st;
+}
+
+void gf_shutdown()
+{
+    std::lock_guard<std::mutex> lock(g_side_mu);
+    for (size_t i = 0; i < g_side_n; i++)
+        (void)hipStreamDestroy(g_side[i].side);
+    g_side_n = 0;
 }
 
 size_t gf_workspace_cap()
@@ -1240,7 +1304,7 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
     char *ws0 = static_cast<char *>(workspace) + header;
     hipStream_t side = nullptr;
     if (fused && chunk >= 2 && !debug_get(kDbgGfOneStream))
-        side = gf_side_stream();
+        side = gf_side_stream(stream);
     for (int i0 = 0; i0 < n; i0 += chunk) {
         const int m = std::min(chunk, n - i0);
         if (side == nullptr || m < 2) {

@@ -1745,6 +1745,12 @@ __global__ __launch_bounds__(16 * f32_tile_h(JCN, SCN)) void jbf_f32_quad_kernel
             const float ws[4] = {w0, w1, w2, w3};
 #pragma unroll
             for (int p = 0; p < 4; p++) {
+                // columns of the span that lie off output p's disk are not taps of p: OpenCV never
+                // reads them, so a NaN / Inf texel there must not reach p (0 * Inf is NaN, and a NaN
+                // distance would index the table out of range).  c, p and hw are wave-uniform: a
+                // scalar branch.
+                if (c - p < -hw || c - p > hw)
+                    continue;
                 float alpha = 0.f;
 #pragma unroll
                 for (int ch = 0; ch < JCN; ch++)

@@ -94,19 +94,32 @@ def guided_filter_u8(guide, src, radius, eps, iterations=1, out=None, workspace=
 
 
 def _cnn_device_consts(torch, device, weights):
+    """(packed weights, sRGB table) on `device`.  Packing is the net-load step
+    (rf_cnn_pack_weights): done once for the shipped weights (cached per device), once per call
+    for caller-supplied ones; the forward pass itself keeps no state in the library."""
     from . import image_utils as iu
     from . import weights as wmod
+    lib = _ffi.load_library()
+
+    def pack(w_host):
+        raw = torch.from_numpy(w_host).to(device)
+        packed = torch.empty_like(raw)
+        _ffi.check(lib.rf_cnn_pack_weights(raw.data_ptr(), packed.data_ptr(),
+                                           _ffi.current_stream_ptr(torch)), "rf_cnn_pack_weights")
+        return packed                       # `raw` may go: the pack is ordered on this stream
+
     if weights is None:
         key = (str(device), "default")
         if key not in _cnn_consts:
-            w = torch.from_numpy(wmod.load_weights()).to(device)
             lut = torch.from_numpy(iu.srgb_byte_lut()).to(device)
-            _cnn_consts[key] = (w, lut)
+            _cnn_consts[key] = (pack(wmod.load_weights()), lut)
+            # other streams may use the cached copy: make it visible to all of them once
+            torch.cuda.current_stream(device).synchronize()
         return _cnn_consts[key]
     w = np.ascontiguousarray(weights, dtype=np.float32).ravel()
     if w.size != _ffi.CNN_NPARAMS:
         raise ValueError("weights must hold %d floats" % _ffi.CNN_NPARAMS)
-    return (torch.from_numpy(w).to(device), torch.from_numpy(iu.srgb_byte_lut()).to(device))
+    return (pack(w), torch.from_numpy(iu.srgb_byte_lut()).to(device))
 
 
 def cnn_reflectance_u8(bgr, weights=None, want_float=True, want_u8=True):
@@ -118,13 +131,14 @@ def cnn_reflectance_u8(bgr, weights=None, want_float=True, want_u8=True):
     if bgr.shape[3] != 3:
         raise ValueError("bgr must have 3 channels")
     n, h, w, _ = bgr.shape
-    wts, lut = _cnn_device_consts(torch, bgr.device, weights)
+    packed, lut = _cnn_device_consts(torch, bgr.device, weights)
     r = torch.empty((n, h, w), dtype=torch.float32, device=bgr.device) if want_float else None
     r8 = torch.empty((n, h, w), dtype=torch.uint8, device=bgr.device) if want_u8 else None
-    rc = lib.rf_cnn_reflectance_u8(bgr.data_ptr(), r.data_ptr() if want_float else None,
-                                   r8.data_ptr() if want_u8 else None, n, h, w, wts.data_ptr(),
-                                   lut.data_ptr(), _ffi.current_stream_ptr(torch))
-    _ffi.check(rc, "rf_cnn_reflectance_u8")
+    rc = lib.rf_cnn_reflectance_packed_u8(bgr.data_ptr(), r.data_ptr() if want_float else None,
+                                          r8.data_ptr() if want_u8 else None, n, h, w,
+                                          packed.data_ptr(), lut.data_ptr(),
+                                          _ffi.current_stream_ptr(torch))
+    _ffi.check(rc, "rf_cnn_reflectance_packed_u8")
     return r, r8
 
 

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(built):
     assert set(names) == set(_ffi.EXPORTS)
     for name in names:
         assert getattr(lib, name) is not None
-    assert lib.rf_version() == 100
+    assert lib.rf_version() == 101
     out = subprocess.check_output(["nm", "-D", "--defined-only", _ffi.LIB_PATH]).decode()
     for name in names:
         assert re.search(r"\bT %s\b" % name, out), name
@@ -112,6 +112,11 @@ def test_argument_validation_needs_no_gpu(built):
     assert lib.rf_gf_u8(p, q, o, 1, 4, 4, 3, 3, 500, 1.0, 1, p, 1 << 20, None) == _ffi.RF_E_UNSUPPORTED
     assert lib.rf_gf_u8(p, q, o, 1, 64, 64, 3, 3, 2, 1.0, 1, p, 16, None) == _ffi.RF_E_WORKSPACE
     assert lib.rf_cnn_reflectance_u8(p, None, None, 1, 4, 4, p, p, None) == _ffi.RF_E_BADARG
+    assert lib.rf_cnn_reflectance_packed_u8(p, None, None, 1, 4, 4, p, p, None) == _ffi.RF_E_BADARG
+    assert lib.rf_cnn_reflectance_packed_u8(p, q, None, 0, 4, 4, None, None, None) == _ffi.RF_OK
+    assert lib.rf_cnn_pack_weights(p, None, None) == _ffi.RF_E_BADARG
+    assert lib.rf_cnn_pack_weights(base, base + 64, None) == _ffi.RF_E_BADARG   # overlapping
+    assert b"overlap" in lib.rf_last_error()
     # 256-byte header (per-image grey flags) + 12 float and 12 double planes
     assert lib.rf_gf_workspace_bytes(1, 100, 200, 3, 3, 45) == 256 + 100 * 200 * 12 * 12
     assert lib.rf_colorize_workspace_bytes(0) == 0 and lib.rf_colorize_workspace_bytes(3) > 0

@@ -195,3 +195,29 @@ def test_gpu_jbf_f32_reference_radius_interior_tiles(gpu):
         assert np.array_equal(got, ref)
         want = co.joint_bilateral_filter_f32(j, s_, -1, 20 / 255.0, 22.0)
         assert np.array_equal(got, want.reshape(got.shape))
+
+
+@pytest.mark.gpu
+def test_gpu_jbf_f32_non_finite_src_stays_inside_its_disk(gpu):
+    """A NaN / Inf src texel reaches exactly the outputs whose disk holds it (OpenCV never reads a
+    texel off the disk): the register-tiled kernel visits the whole bounding span of its four
+    outputs and must not let 0 * Inf leak into the neighbours.  Tiled == untiled, NaNs included."""
+    rf, torch = gpu
+    h, w = 70, 96
+    joint = np.ascontiguousarray(_f(synth.scene_u8(h, w, seed=31)))
+    src = np.ascontiguousarray(_f(synth.scene_u8(h, w, seed=32))[:, :, :1])
+    bad = [(20, 30, np.nan), (50, 61, np.inf), (5, 2, -np.inf)]
+    for y, x, v in bad:
+        src[y, x, 0] = v
+    jd, sd = torch.from_numpy(joint[None]).cuda(), torch.from_numpy(src[None]).cuda()
+    for d, ss in ((-1, 4.0), (9, 2.0)):
+        radius = int(round(ss * 1.5)) if d <= 0 else d // 2
+        got = rf.ops.joint_bilateral_f32(jd, sd, d, 0.2, ss).cpu().numpy()[0]
+        with rf._ffi.debug_options(jbf_f32_untiled=1):
+            ref = rf.ops.joint_bilateral_f32(jd, sd, d, 0.2, ss).cpu().numpy()[0]
+        assert np.array_equal(got, ref, equal_nan=True), (d, ss)
+        yy, xx = np.mgrid[0:h, 0:w]
+        reach = np.zeros((h, w), bool)
+        for y, x, _ in bad:
+            reach |= (yy - y) ** 2 + (xx - x) ** 2 <= radius * radius
+        assert np.isfinite(got[~reach]).all(), (d, ss)

@@ -654,10 +654,131 @@ def test_captured_call_with_forked_guided_filter(env):
     assert torch.equal(got, want)
 
 
+def test_captured_call_with_cnn_and_raw_entry_point_rules(env):
+    """The CNN forward on pre-packed weights (what ops.cnn_reflectance_u8 calls) keeps no state in
+    the library, so the decompose -> filter chain can be captured; the one-call raw-weights entry
+    point refuses its FIRST call on a capturing stream (it would allocate) and is capturable once
+    that stream has a slot; its slot table stays bounded over many streams."""
+    import ctypes
+    from tests import synth
+    rf, co, torch = env
+    lib = rf._ffi.load_library()
+    h, w = 64, 96
+    img = torch.from_numpy(np.stack([synth.scene_u8(h, w, seed=k) for k in (1, 2)])).cuda()
+    want_r, want_r8 = rf.ops.cnn_reflectance_u8(img)
+    want_bf = rf.ops.joint_bilateral_u8(want_r8[..., None].contiguous(), want_r8[..., None].contiguous(),
+                                        -1, 20.0, 5.0, grey_as_bgr=True)
+    packed, lut = rf.ops._cnn_device_consts(torch, img.device, None)
+    r = torch.empty((2, h, w), dtype=torch.float32, device="cuda")
+    r8 = torch.empty((2, h, w, 1), dtype=torch.uint8, device="cuda")
+    bf = torch.empty_like(r8)
+
+    def chain():
+        rc = lib.rf_cnn_reflectance_packed_u8(img.data_ptr(), r.data_ptr(), r8.data_ptr(), 2, h, w,
+                                              packed.data_ptr(), lut.data_ptr(),
+                                              rf._ffi.current_stream_ptr(torch))
+        rf._ffi.check(rc, "rf_cnn_reflectance_packed_u8")
+        rf.ops.joint_bilateral_u8(r8, r8, -1, 20.0, 5.0, out=bf, grey_as_bgr=True)
+        return r, r8, bf
+
+    cap = rf.ops.CapturedCall(chain)
+    r.zero_(), r8.zero_(), bf.zero_()
+    a, b, c = cap.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(a, want_r) and torch.equal(b[..., 0], want_r8) and torch.equal(c, want_bf)
+
+    raw = torch.from_numpy(rf.weights.load_weights()).cuda()
+
+    def raw_call(stream_ptr):
+        return lib.rf_cnn_reflectance_u8(img.data_ptr(), r.data_ptr(), None, 2, h, w,
+                                         raw.data_ptr(), lut.data_ptr(), ctypes.c_void_p(stream_ptr))
+
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        rc_first = raw_call(side.cuda_stream)       # no slot for this stream yet: refused, not captured
+    assert rc_first == rf._ffi.RF_E_UNSUPPORTED and b"captured" in lib.rf_last_error()
+    assert raw_call(side.cuda_stream) == rf._ffi.RF_OK     # eager call makes the slot
+    torch.cuda.synchronize()
+    graph2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph2, stream=side):
+        assert raw_call(side.cuda_stream) == rf._ffi.RF_OK
+    r.zero_()
+    graph2.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(r, want_r)
+    streams = [torch.cuda.Stream() for _ in range(40)]      # more streams than slots
+    for st in streams:
+        assert raw_call(st.cuda_stream) == rf._ffi.RF_OK
+    torch.cuda.synchronize()
+    assert torch.equal(r, want_r)
+
+
+def test_gf_capture_on_one_thread_eager_on_another(env):
+    """Side streams are per caller stream: while one thread captures a two-image guided-filter
+    call into a graph (its side stream joins that capture), another thread calls the filter
+    eagerly on its own stream - the eager results are right, the capture stays valid and its
+    replay gives the eager bytes."""
+    import threading
+    from tests import synth
+    rf, co, torch = env
+    h, w = 200, 260
+    mk = lambda f, seeds: torch.from_numpy(np.stack([f(h, w, seed=k) for k in seeds])).cuda()
+    g1, s1 = mk(synth.flat_guide_u8, (1, 2)), mk(synth.scene_u8, (3, 4))
+    g2, s2 = mk(synth.scene_u8, (5, 6)), mk(synth.reflectance_like_u8, (7, 8))
+    with rf._ffi.debug_options(gf_one_stream=1):
+        want1 = rf.ops.guided_filter_u8(g1, s1, 45, 3.0, iterations=2)
+        want2 = rf.ops.guided_filter_u8(g2, s2, 45, 3.0, iterations=2)
+    out1 = torch.empty_like(s1)
+    ws1 = rf.ops.gf_workspace(2, h, w, 3, 45, s1.device, torch)
+    ws2 = torch.empty_like(ws1)
+    torch.cuda.synchronize()
+    stop = threading.Event()
+    errors, eager_runs = [], [0]
+
+    def eager():
+        try:
+            torch.cuda.set_device(0)
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                while not stop.is_set() or eager_runs[0] < 3:
+                    got = rf.ops.guided_filter_u8(g2, s2, 45, 3.0, iterations=2, workspace=ws2)
+                    st.synchronize()
+                    if not torch.equal(got, want2):
+                        errors.append("eager result differs")
+                    eager_runs[0] += 1
+                    if eager_runs[0] > 200:
+                        break
+        except Exception as exc:               # noqa: BLE001 - reported by the main thread
+            errors.append(repr(exc))
+
+    th = threading.Thread(target=eager)
+    th.start()
+    try:
+        side = torch.cuda.Stream()
+        graphs = []
+        for _ in range(3):
+            graph = torch.cuda.CUDAGraph()
+            # thread_local capture mode: the other thread's allocations and launches are its own business
+            with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+                rf.ops.guided_filter_u8(g1, s1, 45, 3.0, iterations=2, out=out1, workspace=ws1)
+            graphs.append(graph)
+    finally:
+        stop.set()
+        th.join()
+    assert not errors, errors
+    assert eager_runs[0] >= 3
+    for graph in graphs:
+        out1.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out1, want1)
+
+
 def test_two_streams_do_not_share_scratch(env):
-    """Guided-filter workspaces are cached per (device, stream) and the CNN's packed weights live
-    in a per-(device, stream) buffer: calls in flight on two streams give the bytes of the
-    one-stream calls (they used to share planes / one weight buffer per device)."""
+    """Guided-filter workspaces are cached per (device, stream) and every CNN call with its own
+    weights packs them into a buffer of its own: calls in flight on two streams give the bytes of
+    the one-stream calls (they used to share planes / one weight buffer per device)."""
     from tests import synth
     rf, co, torch = env
     h, w = 700, 900
