@@ -80,9 +80,13 @@ def _free_port():
     return port
 
 
-def launch_ranks(n, argv):
+def launch_ranks(n, argv, deadline_s=3600.0):
     """Start one child per GPU (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* as torchrun would set them).
-    The parent never initialises the GPU; rank 0's stdout is this process's stdout."""
+    The parent never initialises the GPU; rank 0's stdout is this process's stdout, the other
+    ranks' stdout goes to this process's stderr (their diagnostics stay visible, the one JSON
+    line stays alone on stdout).  All children are polled together: the first non-zero exit (or
+    the deadline) ends the others, so a rank that dies during start-up cannot leave the rest
+    waiting in a barrier."""
     port = _free_port()
     procs = []
     for rank in range(n):
@@ -90,10 +94,35 @@ def launch_ranks(n, argv):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv),
-                                      env=env, stdout=None if rank == 0 else subprocess.DEVNULL))
+                                      env=env, stdout=None if rank == 0 else sys.stderr))
+    t_end = time.monotonic() + deadline_s
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    live = list(procs)
+    while live and rc == 0:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0:
+                rc = abs(code) or 1
+                sys.stderr.write("bench.py: rank %d exited with %d; stopping the other ranks\n"
+                                 % (procs.index(p), code))
+        if live and rc == 0:
+            if time.monotonic() > t_end:
+                rc = 124
+                sys.stderr.write("bench.py: ranks still running after %.0f s; stopping them\n"
+                                 % deadline_s)
+            else:
+                time.sleep(0.05)
+    for p in live:                      # these are this process's own children, by handle
+        p.terminate()
+    for p in live:
+        try:
+            p.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
     return rc
 
 
@@ -241,11 +270,13 @@ def cpu_baseline(joint0, src0, sigma_color, sigma_spatial, target_s):
                       % (reps, hh, w, mp, t, cores)}
 
 
-def valu_roofline(n, h, w, radius, kernel_ms, taps_per_launch):
+def valu_roofline(n, h, w, radius, kernel_ms, taps_per_launch, clock_mhz=None):
     """Issue-floor time of the launch = column steps x 26 instructions x 2 cycles / (1024 SIMDs
-    x 2.4 GHz).  Column steps per wave follow the kernel's row walk: per tap row, groups of 4
+    x shader clock).  Column steps per wave follow the kernel's row walk: per tap row, groups of 4
     columns covering -hw4 .. hw4+3 (hw = half-width of the disk on that row, hw4 = hw rounded up
-    to a multiple of 4)."""
+    to a multiple of 4).  The clock is the one measured under this launch (`measured_clock_mhz`:
+    a one-wave probe on a second stream, s_memtime over s_memrealtime); `floor_ms_at_2400mhz` is
+    the same floor at the 2.4 GHz peak clock of MI355X_MICROARCH.md."""
     steps_per_wave = 0
     for i in range(-radius, radius + 1):
         hw = int((radius * radius - i * i) ** 0.5)
@@ -253,11 +284,37 @@ def valu_roofline(n, h, w, radius, kernel_ms, taps_per_launch):
         steps_per_wave += 4 * (hw4 // 2 + 1)
     tiles = n * ((w + 63) // 64) * ((h + 63) // 64)
     wave_steps = tiles * 16 * steps_per_wave          # 16 waves per 64x64 tile
-    floor_s = wave_steps * 26 * 2 / (1024 * 2.4e9)
+    cycles = wave_steps * 26 * 2 / 1024.0
+    floor_peak_s = cycles / 2.4e9
+    mhz = clock_mhz if clock_mhz else 2400.0
+    floor_s = cycles / (mhz * 1e6)
     return {"bound": "valu-issue", "instructions_per_column_step": 26,
-            "column_steps_per_launch": wave_steps, "floor_ms": floor_s * 1e3,
-            "frac": floor_s / (kernel_ms * 1e-3), "taps_per_s": taps_per_launch / (kernel_ms * 1e-3),
+            "column_steps_per_launch": wave_steps, "clock_mhz": mhz,
+            "clock_source": ("s_memtime / s_memrealtime probe beside the launch" if clock_mhz
+                             else "2.4 GHz peak (no probe)"),
+            "floor_ms": floor_s * 1e3, "floor_ms_at_2400mhz": floor_peak_s * 1e3,
+            "frac": floor_s / (kernel_ms * 1e-3),
+            "frac_at_2400mhz": floor_peak_s / (kernel_ms * 1e-3),
+            "taps_per_s": taps_per_launch / (kernel_ms * 1e-3),
             "lane_ops_per_tap": VALU_LANE_OPS_PER_S / (taps_per_launch / (kernel_ms * 1e-3))}
+
+
+def measured_clock_mhz(torch, rf, step, kernel_ms):
+    """Shader clock while `step` runs: launch the step, then the one-wave probe
+    (rf_debug_clock_probe) on a second stream for the middle half of the step's duration."""
+    lib = rf._ffi.load_library()
+    out = torch.zeros(2, dtype=torch.int64, device="cuda")
+    side = torch.cuda.Stream()
+    micros = int(max(200, min(200000, kernel_ms * 1e3 * 0.5)))
+    torch.cuda.synchronize()
+    step()
+    time.sleep(min(0.05, kernel_ms * 1e-3 * 0.2))   # let the launch spread over the chip first
+    import ctypes
+    rc = lib.rf_debug_clock_probe(out.data_ptr(), micros, ctypes.c_void_p(side.cuda_stream))
+    rf._ffi.check(rc, "rf_debug_clock_probe")
+    torch.cuda.synchronize()
+    cyc, ticks = (int(v) for v in out.cpu())
+    return 100.0 * cyc / ticks if ticks > 0 else None
 
 
 # --------------------------------------------------------------------------- workloads
@@ -366,6 +423,8 @@ def committed_traffic(n, h, w):
 
 def run_rank(args):
     stub = os.environ.get("RF_BENCH_STUB") == "1"
+    if stub and os.environ.get("RF_BENCH_STUB_FAIL_RANK") == os.environ.get("RANK", "0"):
+        raise SystemExit(3)          # test hook: a rank that dies before the rendezvous
     from reflectance_filtering_amd import sharding
     backend = "gloo" if stub else None
     if not stub and int(os.environ.get("WORLD_SIZE", "1")) > 1:
@@ -406,6 +465,12 @@ def run_rank(args):
     px_total, t_max = sharding.reduce_job(wl.pixels * args.steps, elapsed, world, device=device)
 
     extras = {}
+    clock_mhz = None
+    if rank == 0 and not stub and kind == "jbf" and kernel_ms and kernel_ms > 2.0:
+        try:
+            clock_mhz = measured_clock_mhz(torch, rf, wl.step, kernel_ms)
+        except Exception as exc:                  # noqa: BLE001 - a measurement aid, never fatal
+            sys.stderr.write("bench.py: clock probe failed: %r\n" % (exc,))
     if rank == 0 and not stub and not args.no_extras and kind == "jbf" and n > 1:
         sc, ss = args.sigma_color, args.sigma_spatial
         joint, src, dst = wl.joint, wl.src, wl.dst
@@ -440,13 +505,18 @@ def run_rank(args):
         # driver-timed lines for the other BASELINE configurations (one GPU; not `value`)
         del wl.joint, wl.src, wl.dst
         torch.cuda.empty_cache()
-        for key, cfg, nb in (("c3_chain", "c3", 256), ("c5_gf", "c5", 16)):
+        # C5 runs at its stated shard (128 x 4K per GPU: 10 GB of images + a workspace of up to
+        # 16 GiB) when the device has the room, else at batch 16
+        free_b, _ = torch.cuda.mem_get_info()
+        c5_batch = CONFIGS["c5"][1] if free_b >= (48 << 30) else 16
+        for key, cfg, nb in (("c3_chain", "c3", 256), ("c5_gf", "c5", c5_batch)):
             k2, _, h2, w2 = CONFIGS[cfg]
             w2l = Workload(k2, nb, h2, w2, args, torch, rf, device, seed=1234 + 1000 * int(cfg[1]))
             w2l.step()
             el, kms = w2l.timed_steps(3, 1, sharding)
             gbs = w2l.pixels * w2l.bytes_per_px / (kms * 1e-3) / 1e9
-            extras[key] = {"workload": w2l.name, "value": w2l.pixels * 3 / 1e6 / el, "unit": "MP/s",
+            extras[key] = {"workload": w2l.name, "batch": nb,
+                           "value": w2l.pixels * 3 / 1e6 / el, "unit": "MP/s",
                            "ms_per_step": el / 3 * 1e3, "steps": 3,
                            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
                                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
@@ -481,10 +551,9 @@ def run_rank(args):
                            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                            "traffic_source": (source + " (rocprofv3 --pmc passes of this launch "
                                               "shape; not measured by this run)") if source else None,
-                           "kernel": {"jbf": "jbf_tile64_kernel (name as in profiles/; the launch "
-                                             "is timed through HIP events, not identified by name)",
-                                      "gf3": "gf_stage1 + gf_rowstate + gf_colwalk, 3 passes",
-                                      "chain": "cnn_reflectance + jbf_tile64 (1-channel)"}[kind],
+                           "kernel_note": "the launch is timed through HIP events on its stream, "
+                                          "not identified by name; profiles/ lists the kernels of "
+                                          "the same command under rocprofv3",
                            "kernel_ms": kernel_ms,
                            "algorithmic_bytes_per_launch": launch_px * wl.bytes_per_px}
     if kind == "jbf" and not stub:
@@ -494,7 +563,7 @@ def run_rank(args):
         # the bound that actually limits an exact brute-force bilateral: VALU issue.  The grey
         # tap loop retires 26 VALU wave-instructions per 4-output column step; a gfx950 SIMD
         # issues at most one per 2 cycles (tools/microbench/valu_rates2.hip), 1024 SIMDs, 2.4 GHz.
-        out["valu"] = valu_roofline(n, h, w, radius, kernel_ms, launch_px * taps)
+        out["valu"] = valu_roofline(n, h, w, radius, kernel_ms, launch_px * taps, clock_mhz)
         out["config"]["taps_per_px"] = taps
     out.update(extras)
     if image0 is not None:

@@ -33,6 +33,13 @@ extern "C" {
  * unknown name. */
 int rf_debug_option(const char *name, int value);
 
+/* Measurement aid of bench.py: one wave on `stream` brackets `micros` microseconds of wall time
+ * (s_memrealtime, 100 MHz) with the shader-cycle counter (s_memtime), sleeping in between, and
+ * writes {shader cycles, 100 MHz ticks} to the two device words at out2.  Launched on a second
+ * stream beside a running kernel it reads the clock the chip holds under that kernel's load:
+ * MHz = 100 * out2[0] / out2[1]. */
+int rf_debug_clock_probe(unsigned long long *out2, int micros, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

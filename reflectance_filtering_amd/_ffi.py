@@ -27,7 +27,7 @@ EXPORTS = ("rf_version", "rf_last_error", "rf_shutdown", "rf_jbf_u8", "rf_gf_wor
            "rf_gf_f32_workspace_bytes", "rf_gf_f32")
 
 # include/reflectance_filtering_debug.h: test / benchmark switches, not part of the boundary
-DEBUG_EXPORTS = ("rf_debug_option",)
+DEBUG_EXPORTS = ("rf_debug_option", "rf_debug_clock_probe")
 
 _lib = None
 _lock = threading.Lock()
@@ -88,6 +88,8 @@ def load_library():
         lib.rf_whdr_f32.restype = ci
         lib.rf_debug_option.argtypes = [ctypes.c_char_p, ci]
         lib.rf_debug_option.restype = ci
+        lib.rf_debug_clock_probe.argtypes = [vp, ci, vp]
+        lib.rf_debug_clock_probe.restype = ci
         _lib = lib
         return lib
 

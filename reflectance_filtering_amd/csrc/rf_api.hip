@@ -48,6 +48,36 @@ extern "C" int rf_debug_option(const char *name, int value)
     return rf::fail(RF_E_BADARG, "rf_debug_option: unknown option '%s'", name ? name : "(null)");
 }
 
+// One wave that brackets `micros` microseconds of wall time (s_memrealtime: 100 MHz, constant)
+// with the shader-cycle counter (s_memtime) and sleeps in between: launched on a second stream
+// next to a running kernel it reads the clock the chip holds under THAT kernel's load.
+__global__ void clock_probe_kernel(unsigned long long *out, unsigned long long ticks)
+{
+    if (threadIdx.x != 0)
+        return;
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < ticks) {
+        __builtin_amdgcn_s_sleep(64);
+        r1 = __builtin_amdgcn_s_memrealtime();
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    r1 = __builtin_amdgcn_s_memrealtime();
+    out[0] = c1 - c0;
+    out[1] = r1 - r0;
+}
+
+extern "C" int rf_debug_clock_probe(unsigned long long *out2, int micros, void *stream)
+{
+    if (!out2 || micros < 1 || micros > 1000000)
+        return rf::fail(RF_E_BADARG, "rf_debug_clock_probe: bad argument");
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out2,
+                       (unsigned long long)micros * 100ull);
+    RF_HIP_CHECK(hipGetLastError());
+    return RF_OK;
+}
+
 extern "C" int rf_version(void) { return RF_VERSION; }
 
 extern "C" const char *rf_last_error(void) { return rf::last_error_buf(); }

@@ -67,3 +67,38 @@ def test_bench_configs_name_the_baseline_shapes():
     assert bench.CONFIGS["c5"] == ("gf3", 128, 2160, 3840)       # 1024 images over 8 GPUs
     assert bench.CONFIGS["c3"] == ("chain", 256, 333, 500)
     assert bench.CONFIGS["north_star"] == ("jbf", 256, 1080, 1920)
+
+
+def test_bench_stops_all_ranks_when_one_dies():
+    """Rank 1 exits before the rendezvous: bench.py ends the surviving rank and returns the
+    failure instead of sitting in the barrier until the process-group timeout."""
+    import time
+    t0 = time.monotonic()
+    rc, out, err = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "1",
+                               "--height", "8", "--width", "8"], {"RF_BENCH_STUB_FAIL_RANK": "1"},
+                              timeout=120)
+    assert rc == 3 and out is None
+    assert "rank 1 exited with 3" in err
+    assert time.monotonic() - t0 < 60
+
+
+def test_scale_report_tabulates_the_curve(tmp_path, monkeypatch):
+    """tools/scale_report.py: one command for the 1 -> N curve (here 1 and 2 stub ranks on gloo):
+    absolute MP/s, ratio to one GPU, skipped counts named."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("scale_report",
+                                                  os.path.join(root, "tools", "scale_report.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setenv("RF_BENCH_STUB", "1")
+    for key in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        monkeypatch.delenv(key, raising=False)
+    out = tmp_path / "scale.json"
+    doc = mod.main(["--gpus", "1,2", "--steps", "2", "--warmup", "0", "--batch", "2",
+                    "--out", str(out)])
+    assert [c["n_gpus"] for c in doc["curve"]] == [1, 2] and doc["skipped"] == []
+    assert doc["curve"][0]["ratio_to_one_gpu"] == 1.0
+    assert 1.5 < doc["curve"][1]["ratio_to_one_gpu"] < 2.2       # the stub step is a fixed sleep
+    assert out.exists()

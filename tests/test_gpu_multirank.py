@@ -84,3 +84,48 @@ def test_batch_front_end_two_ranks_equal_one(gpu, tmp_path):
     for f in files:
         with open(str(one / f), "rb") as a, open(str(two / f), "rb") as b:
             assert a.read() == b.read(), f
+
+
+def test_sharding_helpers_over_rccl_on_one_device(gpu):
+    """The `nccl` (= RCCL) branch of sharding.barrier / reduce_job - device-side barrier with
+    device_ids, device tensors in the two scalar all-reduces - run through a real RCCL
+    communicator.  A 1-GPU box admits a group of one rank only (RCCL refuses two ranks on one
+    device), which still drives every call of that branch; on a box with >= 2 devices the same
+    script runs two ranks, one per device."""
+    script = r'''
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from reflectance_filtering_amd import sharding
+rank, world, local = sharding.init_distributed(backend="nccl") if int(os.environ["WORLD_SIZE"]) > 1 else (0, 1, 0)
+torch.cuda.set_device(local)
+if world == 1:
+    dist.init_process_group(backend="nccl", rank=0, world_size=1)
+assert dist.get_backend() == "nccl"
+dev = torch.device("cuda", local)
+sharding.barrier(2)                     # world_size argument only guards the call
+units, secs = sharding.reduce_job(100.0 + rank, 0.5 + rank, 2, device=dev)
+n = dist.get_world_size()
+assert units == sum(100.0 + r for r in range(n)), units
+assert secs == 0.5 + (n - 1), secs
+sharding.barrier(2)
+dist.destroy_process_group()
+print("ok", n)
+''' % ROOT
+    world = 2 if gpu.cuda.device_count() >= 2 else 1
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for rank in range(world):
+        env = _clean_env(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                         MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                         HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", script], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    for p in procs:
+        o, e = p.communicate(timeout=600)
+        assert p.returncode == 0, e.decode()[-3000:]
+        assert o.decode().strip().endswith("ok %d" % world)

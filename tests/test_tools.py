@@ -1,0 +1,61 @@
+"""CPU suite: the one-command reports under tools/ (their logic, not their numbers)."""
+import importlib.util
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load(name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "tools", name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_t2_report_without_opencv(tmp_path, monkeypatch):
+    monkeypatch.setitem(sys.modules, "cv2", None)          # import cv2 -> ImportError
+    out = tmp_path / "t2.json"
+    assert _load("t2_report").main(["--out", str(out), "--no-gpu"]) == 3
+    doc = json.loads(out.read_text())
+    assert doc["opencv"] is None and doc["cases"] == [] and "unpinned" in doc["verdict"]
+
+
+def test_t2_report_with_a_stand_in_opencv(tmp_path, monkeypatch):
+    """A stand-in `cv2` (its ximgproc answers with the oracle, one case off by one grey level)
+    drives the whole report path: every F5-F7 filter case compared, the odd case named."""
+    from oracle import c_oracle as co
+    calls = {"n": 0}
+
+    def jbf(joint, src, d, sc, ss):
+        calls["n"] += 1
+        res = co.joint_bilateral_filter(joint, src, d, sc, ss)
+        if calls["n"] == 1:
+            res = res.copy()
+            res.flat[0] = res.flat[0] + 1 if res.flat[0] < 255 else 254
+        return res
+
+    fake = types.ModuleType("cv2")
+    fake.__version__ = "0.0-stand-in"
+    fake.error = RuntimeError
+    fake.getBuildInformation = lambda: "stand-in build"
+    fake.getNumThreads = lambda: 1
+    fake.ximgproc = types.SimpleNamespace(
+        jointBilateralFilter=jbf,
+        guidedFilter=lambda guide, src, radius, eps: co.guided_filter(guide, src, radius, eps))
+    monkeypatch.setitem(sys.modules, "cv2", fake)
+    out = tmp_path / "t2.json"
+    assert _load("t2_report").main(["--out", str(out), "--no-gpu"]) == 0
+    doc = json.loads(out.read_text())
+    with open(os.path.join(ROOT, "tests", "golden", "filter_vectors.json")) as fh:
+        want = sorted(k for k, e in json.load(fh)["cases"].items() if e["kind"] in ("jbf", "gf"))
+    assert [c["case"] for c in doc["cases"]] == want
+    assert doc["opencv"] == "0.0-stand-in" and doc["hip_path"] is False
+    off = [c for c in doc["cases"] if c["oracle_vs_opencv"]["max_abs"]]
+    assert len(off) == 1 and off[0]["oracle_vs_opencv"]["max_abs"] == 1
+    assert doc["worst_max_abs"] == 1 and "differs" in doc["verdict"]
+    assert all(c["frozen_vector_vs_opencv"]["max_abs"] <= 1 for c in doc["cases"])
