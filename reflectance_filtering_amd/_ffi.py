@@ -90,6 +90,12 @@ def load_library():
         lib.rf_debug_option.restype = ci
         lib.rf_debug_clock_probe.argtypes = [vp, ci, vp]
         lib.rf_debug_clock_probe.restype = ci
+        # RF_DEBUG_OPTIONS="name=value,...": preset the test / benchmark switches of
+        # include/reflectance_filtering_debug.h for a whole process (timing experiments only)
+        for item in filter(None, os.environ.get("RF_DEBUG_OPTIONS", "").split(",")):
+            name, _, value = item.partition("=")
+            if lib.rf_debug_option(name.strip().encode(), int(value or 1)) < 0:
+                raise RFError("RF_DEBUG_OPTIONS: unknown debug option %r" % name)
         _lib = lib
         return lib
 

@@ -27,7 +27,7 @@
 // they run the one-channel instantiation with the result byte written three times (1/3 of the
 // per-channel planes).  Every stage is launched in both instantiations; workgroups of the one
 // that does not apply to their image exit at once.
-#include "rf_common.hpp"
+#include "rf_gf_fused.hpp"
 
 #include <algorithm>
 #include <mutex>
@@ -182,13 +182,6 @@ __global__ __launch_bounds__(256) void gf_grey_probe_kernel(const uint8_t *__res
         colour[blockIdx.y] = 1;
 }
 
-// Does this workgroup's instantiation apply to image img?  (colour == nullptr: no choice to make)
-template <int SCN>
-__device__ inline bool wrong_variant(const int *__restrict__ colour, int img)
-{
-    return colour != nullptr && (colour[img] != 0) != (SCN == 3);
-}
-
 // grid: (strips, row segments, images).  ab: [img][SPX][h][w][4] float (g<3 alpha, g=3 beta).
 // SCN = src channels computed, SPX = src bytes per pixel (SCN, or 3 with SCN = 1 for a grey
 // 3-channel image whose first channel stands for all three).
@@ -232,6 +225,9 @@ __global__ __launch_bounds__(stage1_threads(SCN)) void gf_stage1_kernel(
         for (int q = 0; q < NQ; q++)
             V[k][q] = 0;
 
+    // (Byte loads, 3 x (3 + SCN) per row step and thread, are not what limits this kernel: fetching
+    // a thread's three pixels as one 12-byte load and picking the bytes apart was measured 10 %
+    // SLOWER - the extra VALU work costs more than the vector-memory instructions it saves.)
     auto add_row = [&](int yy, bool add) {
         const int gy = border_interpolate(yy, h, RF_BORDER_REFLECT);
 #pragma unroll
@@ -352,7 +348,6 @@ __global__ __launch_bounds__(stage1_threads(SCN)) void gf_stage1_kernel(
 // the border-extended row left to right; tiles are transposed through LDS so that global
 // loads/stores stay row-contiguous.
 // ------------------------------------------------------------------------------------------
-constexpr int kBRows = 64;
 constexpr int kBChunk = 32;
 
 // planes: [img][src_np][h][w] (il = 1) or [img][src_np / 4][h][w][4] (il = 4: groups of four
@@ -500,418 +495,6 @@ __global__ __launch_bounds__(64 * 4 * SCN) void gf_colsum_apply_kernel(
             }
         }
     }
-}
-
-// ------------------------------------------------------------------------------------------
-// stage 2, fused form (radii 45 and 52, the reference's parameter sets): the double row sums
-// never reach HBM.
-//
-//   gf_rowstate_kernel   walks every row of every alpha/beta plane once (one lane per row, the
-//                        same RowSum<float,double> chain as gf_rowsum_kernel) but stores the
-//                        running sum only at every 16th column: states[plane][x/16][row].
-//   gf_colwalk_kernel    one wave owns 16 columns x the 4 planes (alpha_0..2, beta) of one src
-//                        channel and walks down the image in sub-tiles of T rows (2R = NSUB T).
-//                        Row phase (lane = plane x row): restart each row chain from its stored
-//                        state and rebuild the sub-tile's T x 16 row sums in LDS.  Column phase
-//                        (lane = plane x column): ColumnSum<double,float> down the sub-tile; the
-//                        value leaving the window, R[y - r], is the value that entered 2r steps
-//                        earlier in the same lane, so it is kept in a register FIFO of 2r doubles
-//                        (statically indexed: the loop body is one period of NSUB sub-tiles,
-//                        fully unrolled).  After each sub-tile the four means of a pixel meet in
-//                        LDS and q = beta + sum alpha_g I_g is formed and stored.
-//
-// Every double add happens in the order of the two-kernel form above, so the bytes are the same;
-// measured memory-side traffic of a whole pass at 8 x 4K, colour src: 548 -> 215 B/px
-// (profiles/r02base_gf_cnn.md, r02_gf_cnn.md).
-// ------------------------------------------------------------------------------------------
-constexpr int kSB = 16;      // columns per state block and per column-walk wave
-
-// planes: [img][src_np / 4][h][w][4] (the four planes of a src channel interleaved per pixel);
-// states: [img * np + plane][nb][h], nb = ceil(w / 16); states[..][b][row] = RowSum at column 16 b.
-// grid: (plane groups of the chunk) x (64-row blocks); one workgroup = 4 waves = the 4 planes of
-// a group, lane = row, walking the border-extended row ext[i] = S[bi(i - r)] from its left end.
-// The workgroup fetches a chunk of 16 columns x 64 rows as float4 pixels (256 contiguous bytes per
-// image row and load) and hands each wave its plane through LDS (20 KB).  The value leaving the
-// window, ext[i - ks], is the value that entered ks steps earlier in the same lane: it is kept in
-// a register FIFO of F >= ks floats, F a multiple of 16 (slot = step mod F, static because the
-// loop body is one period of F steps, fully unrolled) - no second read.  The stream is prefixed
-// with PAD dummy steps so that every chunk of 16 steps is an aligned run of 16 source columns.
-// A workgroup walks its rows alone from end to end (252 chunks at 4K), so the time of the kernel
-// is the time of a chunk: two chunks of loads are in flight, and a full chunk reads its 16
-// operands with four 16-byte LDS reads and forms all differences before the chain of dependent
-// adds (one LDS round trip per chunk, not per step).  Measured at 8 x 4K (planar layout, one wave
-// per plane, one chunk in flight: 0.36 ms grey, 0.99 ms colour): 0.33 / 0.83 ms; without the
-// global loads (timing-only build) 0.20 / 0.40 ms - the rest is the issue rate of the one wave a
-// SIMD holds when a grey batch gives every CU a single workgroup.  Capping the registers for a
-// third / fourth workgroup per CU spills and is slower.
-template <int R>
-__global__ __launch_bounds__(256) void gf_rowstate_kernel(const float *__restrict__ planes,
-                                                          double *__restrict__ states, int h, int w,
-                                                          int row_blocks, int np,
-                                                          const int *__restrict__ colour, int src_np,
-                                                          int nb)
-{
-    constexpr int KS = 2 * R + 1;
-    constexpr int F = (KS + 15) & ~15;
-    constexpr int NCH = F / 16;
-    constexpr int PAD = (16 - R % 16) % 16;  // step t <-> extended index i = t - PAD, column i - R
-    static_assert(KS + PAD <= 2 * F, "the window fills within the two peeled periods");
-    const int ng = np / 4;                     // plane groups (src channels) per image
-    const int grp = blockIdx.x / row_blocks;   // plane group across the chunk of images
-    const int img = grp / ng, gq = grp - img * ng;
-    if (colour != nullptr && gq >= 1 && colour[img] == 0)
-        return;  // grey 3-channel images only carry the 4 planes of their first channel
-    __shared__ __align__(16) float tE[4][kBRows][20];  // pitch 20: 16-byte rows, conflict-free
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // the wave's plane of the group
-    const int row0 = (blockIdx.x - grp * row_blocks) * kBRows;
-    const float4 *S4 =
-        reinterpret_cast<const float4 *>(planes + ((size_t)img * src_np + gq * 4) * h * w);
-    double *ST = states + ((size_t)img * np + gq * 4 + wv) * nb * h + row0 + lane;
-    const int total = w + 2 * R + PAD;  // steps
-    // loader role: the workgroup fetches the chunk's 64 rows x 16 columns as 1024 float4 (all
-    // four planes of a pixel), thread t the pixels t, t + 256, ...: 16 consecutive threads read
-    // 256 contiguous bytes of one image row
-    const int cc = tid & 15;
-    const bool row_ok = row0 + lane < h;
-    uint32_t srow[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-        srow[k] = (uint32_t)min(row0 + ((tid + 256 * k) >> 4), h - 1) * (uint32_t)w;
-
-    // two chunks in flight (A: even chunks, B: odd ones): a workgroup walks its rows alone, one
-    // chunk after the other, so the time of a chunk is the memory latency it cannot hide
-    float4 preA[4], preB[4];
-    // (a chunk away from both ends of the row needs no border arithmetic; pixel offsets fit 32
-    //  bits - the host admits images below 2^28 pixels here - so a load is SGPR base + byte offset)
-#define RF_RS_FETCH(t0_, BUF)                                                                \
-    do {                                                                                     \
-        const int x0_ = (t0_) - PAD - R;                                                     \
-        int sx_ = x0_ + cc;                                                                  \
-        if (x0_ < 0 || x0_ + 15 >= w || (t0_) + 15 >= total)                                 \
-            sx_ = border_interpolate(min((t0_) + cc, total - 1) - PAD - R, w,                \
-                                     RF_BORDER_REFLECT);                                     \
-        _Pragma("unroll") for (int k = 0; k < 4; k++) BUF[k] = *reinterpret_cast<const float4 *>( \
-            reinterpret_cast<const char *>(S4) + ((srow[k] + (uint32_t)sx_) << 4));          \
-    } while (0)
-    double s = 0.0;
-    float fifo[F];
-    // one chunk of 16 steps; PER = period (0, 1: peeled, window still filling; 2: steady state),
-    // KCH = chunk of the period: step t = t0 + c with (t mod F) = KCH*16 + c static
-#define RF_RS_CHUNK(PER, KCH, t0_, BUF)                                                      \
-    do {                                                                                     \
-        const int t0c_ = (t0_);                                                              \
-        if (t0c_ < total) {                                                                  \
-            __syncthreads();                                                                 \
-            _Pragma("unroll") for (int k = 0; k < 4; k++)                                    \
-            {                                                                                \
-                const int r_ = (tid + 256 * k) >> 4;                                         \
-                tE[0][r_][cc] = BUF[k].x;                                                    \
-                tE[1][r_][cc] = BUF[k].y;                                                    \
-                tE[2][r_][cc] = BUF[k].z;                                                    \
-                tE[3][r_][cc] = BUF[k].w;                                                    \
-            }                                                                                \
-            __syncthreads();                                                                 \
-            if (t0c_ + 32 < total)                                                           \
-                RF_RS_FETCH(t0c_ + 32, BUF);                                                 \
-            if ((PER) == 2 && t0c_ + 16 <= total) {                                          \
-                /* full chunk in the steady state: the 16 operands first (16-byte LDS reads), */ \
-                /* the differences against the FIFO (the slot a step reads is overwritten    */ \
-                /* F - KS steps later), then the dependent adds: one LDS round trip per      */ \
-                /* chunk instead of one per step, no per-step branch                         */ \
-                float4 e4_[4];                                                               \
-                _Pragma("unroll") for (int c4 = 0; c4 < 4; c4++)                             \
-                    e4_[c4] = *reinterpret_cast<const float4 *>(&tE[wv][lane][4 * c4]);      \
-                const float e_[16] = {e4_[0].x, e4_[0].y, e4_[0].z, e4_[0].w, e4_[1].x, e4_[1].y, \
-                                      e4_[1].z, e4_[1].w, e4_[2].x, e4_[2].y, e4_[2].z, e4_[2].w, \
-                                      e4_[3].x, e4_[3].y, e4_[3].z, e4_[3].w};               \
-                _Pragma("unroll") for (int hh = 0; hh < 2; hh++)                             \
-                {                                                                            \
-                    double d_[8];                                                            \
-                    _Pragma("unroll") for (int c8 = 0; c8 < 8; c8++)                         \
-                        d_[c8] = (double)e_[8 * hh + c8] -                                   \
-                                 (double)fifo[((KCH) * 16 + 8 * hh + c8 + F - (KS % F)) % F]; \
-                    _Pragma("unroll") for (int c8 = 0; c8 < 8; c8++)                         \
-                    {                                                                        \
-                        const int c = 8 * hh + c8;                                           \
-                        s += d_[c8];                                                         \
-                        if (((c - PAD - KS + 1) & (kSB - 1)) == 0 && row_ok)                 \
-                            ST[(size_t)((t0c_ + c - PAD - KS + 1) >> 4) * h] = s;            \
-                    }                                                                        \
-                }                                                                            \
-                _Pragma("unroll") for (int c = 0; c < 16; c++) fifo[(KCH) * 16 + c] = e_[c]; \
-            } else                                                                           \
-            _Pragma("unroll") for (int c = 0; c < 16; c++)                                   \
-            {                                                                                \
-                const int tp_ = (KCH) * 16 + c;           /* t mod F */                      \
-                const int ip_ = (PER) * F + tp_ - PAD;     /* i (exact in the peeled periods) */ \
-                if ((PER) < 2 && ip_ < 0) {                                                  \
-                    /* dummy step in front of the row */                                     \
-                } else if (t0c_ + c < total) {                                               \
-                    const float e_ = tE[wv][lane][c];                                        \
-                    if ((PER) < 2 && ip_ < KS)                                               \
-                        s += (double)e_;                                                     \
-                    else                                                                     \
-                        s += (double)e_ - (double)fifo[(tp_ + F - (KS % F)) % F];            \
-                    fifo[tp_] = e_;                                                          \
-                    const int o_ = t0c_ + c - PAD - KS + 1; /* output column of this RowSum */ \
-                    if (o_ >= 0 && (o_ & (kSB - 1)) == 0 && row_ok)                          \
-                        ST[(size_t)(o_ >> 4) * h] = s;                                       \
-                }                                                                            \
-            }                                                                                \
-        }                                                                                    \
-    } while (0)
-    // P0 = buffer of the period's first chunk (chunks alternate A, B)
-#define RF_RS_PERIOD(PER, t0_, P0, P1)                                                       \
-    do {                                                                                     \
-        RF_RS_CHUNK(PER, 0, (t0_), P0);                                                      \
-        RF_RS_CHUNK(PER, 1, (t0_) + 16, P1);                                                 \
-        RF_RS_CHUNK(PER, 2, (t0_) + 32, P0);                                                 \
-        RF_RS_CHUNK(PER, 3, (t0_) + 48, P1);                                                 \
-        RF_RS_CHUNK(PER, 4, (t0_) + 64, P0);                                                 \
-        RF_RS_CHUNK(PER, 5, (t0_) + 80, P1);                                                 \
-        if constexpr (NCH > 6)                                                               \
-            RF_RS_CHUNK(PER, 6, (t0_) + 96, P0);                                             \
-    } while (0)
-    static_assert(NCH == 6 || NCH == 7, "period of 96 or 112 steps");
-    RF_RS_FETCH(0, preA);
-    RF_RS_FETCH(16, preB);
-    if constexpr (NCH == 6) {
-        RF_RS_PERIOD(0, 0, preA, preB);
-        RF_RS_PERIOD(1, F, preA, preB);
-        for (int t0 = 2 * F; t0 < total; t0 += F)
-            RF_RS_PERIOD(2, t0, preA, preB);
-    } else {  // 7 chunks per period: the buffers swap roles from one period to the next
-        RF_RS_PERIOD(0, 0, preA, preB);
-        RF_RS_PERIOD(1, F, preB, preA);
-        for (int t0 = 2 * F; t0 < total; t0 += 2 * F) {
-            RF_RS_PERIOD(2, t0, preA, preB);
-            RF_RS_PERIOD(2, t0 + F, preB, preA);
-        }
-    }
-#undef RF_RS_PERIOD
-#undef RF_RS_CHUNK
-#undef RF_RS_FETCH
-}
-
-// grid: 8 * ceil(items / 8) single-wave workgroups; items = images x SCN x nb, walked so that each
-// XCD (workgroup id mod 8) owns a contiguous run of column blocks: a block's "leaving" operands
-// are the "entering" operands of the block ~1.4 places to its left, served by that XCD's L2.
-//
-// The walk advances in sub-tiles of T padded rows (2R = NSUB * T; T = 15 for R = 45, 13 for 52):
-//   row phase     lane = (plane, row): 4 x T chains of 15 steps from the stored states -> Rt (LDS)
-//   column phase  lane = (plane, column): T steps of ColumnSum<double,float>; FIFO slot of step jj
-//                 of the k-th sub-tile of a period = k T + jj (the period loop is unrolled)
-//   flush         the T x 16 finished pixels: q = beta + a0 I0 + a1 I1 + a2 I2 -> uint8
-// One wave per workgroup: no s_barrier anywhere (__syncthreads() is the LDS fence of the wave).
-// The wave hides memory latency itself: operands and states of sub-tile u+1 and the guide bytes of
-// sub-tile u are requested before sub-tile u's chains run.
-template <int R, int T, int SCN, int SPX>
-__global__ __launch_bounds__(64) void gf_colwalk_kernel(
-    const float *__restrict__ ab, const double *__restrict__ states,
-    const uint8_t *__restrict__ guide, uint8_t *__restrict__ dst, int h, int w, int nb,
-    int n_items, const int *__restrict__ colour)
-{
-    constexpr int KS = 2 * R + 1;
-    constexpr int NSUB = 2 * R / T;
-    static_assert(NSUB * T == 2 * R && 4 * T <= 64 && (T & 1), "sub-tile height");
-    constexpr int NG = (T * 12 + 63) / 64;  // guide dwords per lane and sub-tile
-    constexpr int NF = (T * kSB + 63) / 64; // flush pixels per lane and sub-tile
-    const int per_xcd = (n_items + 7) >> 3;
-    const int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if ((int)(blockIdx.x >> 3) >= per_xcd || item >= n_items)
-        return;
-    const int b = item % nb;
-    const int s_ch = (item / nb) % SCN;
-    const int img = item / (nb * SCN);
-    if (wrong_variant<SCN>(colour, img))
-        return;
-
-    __shared__ double Rt[64][T];                              // row sums [plane*16 + col][row]
-    __shared__ float stE[4 * T][kSB + 1], stL[4 * T][kSB + 1]; // operands [plane*T + row][col]
-    __shared__ float xch[T][4][kSB];                          // means of the sub-tile's rows
-    __shared__ int rowtab[2][T + 1];                          // image row of each padded row
-    __shared__ uint32_t rowoff[2][T + 1];                     // ... times 16 w (byte offset of the row in a plane group)
-    __shared__ uint32_t gst[T][12];                           // guide bytes of the output rows
-
-    const int lane = threadIdx.x;
-    const int g4 = lane >> 4, cc = lane & 15;  // loader and column role: plane, column
-    const int cp = lane / T, cl = lane - cp * T;  // chain role (lane < 4T): plane, row
-    const bool chain = lane < 4 * T;
-    const size_t npx = (size_t)h * w;
-    constexpr int np = 4 * SPX;
-    const float *abg = ab + ((size_t)img * np + 4 * s_ch) * npx;          // planes 4s .. 4s+3
-    const double *stg = states + ((size_t)img * np + 4 * s_ch) * nb * h;  // their states
-    const uint8_t *gimg = guide + (size_t)img * npx * 3;
-    uint8_t *dimg = dst + (size_t)img * npx * SPX;
-    // RowSum at output column o = 16 b + cc (cc >= 1):  + ext[o + 2r] - ext[o - 1], ext[i] = S[bi(i - r)]
-    // per-lane BYTE offsets from the wave-uniform base abg of the channel's plane group
-    // ([h][w][4] floats; 32 bits: the host admits images of less than 2^28 pixels here), so that
-    // base + zero-extended (row offset + lane offset) is the whole address computation
-    const uint32_t oe = 4u * (uint32_t)g4 +
-                        16u * (uint32_t)border_interpolate(b * kSB + cc + R, w, RF_BORDER_REFLECT);
-    const uint32_t ol = 4u * (uint32_t)g4 +
-                        16u * (uint32_t)border_interpolate(b * kSB + cc - 1 - R, w, RF_BORDER_REFLECT);
-    const char *abgb = reinterpret_cast<const char *>(abg);
-    const double *Ps = stg + ((size_t)min(cp, 3) * nb + b) * h;
-    const double scale = 1.0 / (double)(KS * KS);
-    const int nsub = (h + 2 * R + T - 1) / T;  // > NSUB
-    const int jmax = h + 2 * R - 1;
-    const uint32_t gbytes = (uint32_t)(npx * 3);
-
-    float pe[T], pl[T];
-    double pst = 0.0;
-    uint32_t gpre[NG];
-    /* padded row -> image row (BORDER_REFLECT) */
-#define RF_ROWTAB(u_)                                                                        \
-    do {                                                                                     \
-        if (lane < T) {                                                                      \
-            const int row_ = border_interpolate(min((u_) * T + lane, jmax) - R, h,           \
-                                                RF_BORDER_REFLECT);                          \
-            rowtab[(u_) & 1][lane] = row_;                                                   \
-            rowoff[(u_) & 1][lane] = 16u * (uint32_t)row_ * (uint32_t)w;                     \
-        }                                                                                    \
-    } while (0)
-#define RF_FETCH(u_)                                                                         \
-    do {                                                                                     \
-        _Pragma("unroll") for (int L = 0; L < T; L++)                                        \
-        {                                                                                    \
-            const uint32_t ro_ = rowoff[(u_) & 1][L];                                        \
-            pe[L] = *reinterpret_cast<const float *>(abgb + (oe + ro_));                     \
-            pl[L] = *reinterpret_cast<const float *>(abgb + (ol + ro_));                     \
-        }                                                                                    \
-        if (chain)                                                                           \
-            pst = Ps[rowtab[(u_) & 1][cl]];                                                  \
-    } while (0)
-    /* guide bytes of output rows y0 .. y0+T-1, 48 contiguous bytes per row */
-#define RF_GUIDE_FETCH(y0_)                                                                  \
-    do {                                                                                     \
-        _Pragma("unroll") for (int k = 0; k < NG; k++)                                       \
-        {                                                                                    \
-            const int idx_ = lane + 64 * k;                                                  \
-            const int gy_ = min((y0_) + idx_ / 12, h - 1);                                   \
-            const uint32_t off_ = ((uint32_t)gy_ * w + b * kSB) * 3 + (idx_ % 12) * 4;       \
-            uint32_t v_ = 0;                                                                 \
-            if (off_ + 4 <= gbytes) {                                                        \
-                __builtin_memcpy(&v_, gimg + off_, 4);                                       \
-            } else {                                                                         \
-                for (int q = 0; q < 4; q++)                                                  \
-                    if (off_ + q < gbytes)                                                   \
-                        v_ |= (uint32_t)gimg[off_ + q] << (8 * q);                           \
-            }                                                                                \
-            gpre[k] = v_;                                                                    \
-        }                                                                                    \
-    } while (0)
-
-    double SUM = 0.0;
-    double fifo[2 * R];  // R[y - r] is what entered 2r steps ago: slot = step mod 2r, all static
-    // one sub-tile; KSLOT = its place in the FIFO period, FILL = prologue (padded rows -r .. r-1)
-#define RF_SUB(KSLOT, FILL, u_)                                                              \
-    do {                                                                                     \
-        const int uu_ = (u_);                                                                \
-        RF_ROWTAB(uu_ + 1);                                                                  \
-        _Pragma("unroll") for (int L = 0; L < T; L++)                                        \
-        {                                                                                    \
-            stE[g4 * T + L][cc] = pe[L];                                                     \
-            stL[g4 * T + L][cc] = pl[L];                                                     \
-        }                                                                                    \
-        double s_ = pst;                                                                     \
-        __syncthreads();                                                                     \
-        if (!(FILL))                                                                         \
-            RF_GUIDE_FETCH((uu_ - NSUB) * T);                                                \
-        if (uu_ + 1 < nsub)                                                                  \
-            RF_FETCH(uu_ + 1);                                                               \
-        if (chain) {                                                                         \
-            /* all operand differences first (independent LDS reads and conversions), then   */ \
-            /* the chain of dependent adds: the wave is alone on its SIMD, nothing else hides */ \
-            /* an LDS round trip per step                                                     */ \
-            double d_[kSB];                                                                  \
-            _Pragma("unroll") for (int c = 1; c < kSB; c++)                                  \
-                d_[c] = (double)stE[lane][c] - (double)stL[lane][c];                         \
-            Rt[cp * kSB][cl] = s_;                                                           \
-            _Pragma("unroll") for (int c = 1; c < kSB; c++)                                  \
-            {                                                                                \
-                s_ += d_[c];                                                                 \
-                Rt[cp * kSB + c][cl] = s_;                                                   \
-            }                                                                                \
-        }                                                                                    \
-        __syncthreads();                                                                     \
-        {                                                                                    \
-            /* the sub-tile's row sums first (independent LDS reads), then the dependent chain */ \
-            double v_[T];                                                                    \
-            _Pragma("unroll") for (int jj = 0; jj < T; jj++) v_[jj] = Rt[lane][jj];          \
-            _Pragma("unroll") for (int jj = 0; jj < T; jj++)                                 \
-            {                                                                                \
-                if (FILL) {                                                                  \
-                    SUM += v_[jj];                                                           \
-                } else {                                                                     \
-                    const double s0_ = SUM + v_[jj];                                         \
-                    xch[jj][g4][cc] = (float)(s0_ * scale);                                  \
-                    SUM = s0_ - fifo[(KSLOT) * T + jj];                                      \
-                }                                                                            \
-                fifo[(KSLOT) * T + jj] = v_[jj];                                             \
-            }                                                                                \
-        }                                                                                    \
-        if (!(FILL)) {                                                                       \
-            _Pragma("unroll") for (int k = 0; k < NG; k++)                                   \
-            {                                                                                \
-                const int idx_ = lane + 64 * k;                                              \
-                if (idx_ < T * 12)                                                           \
-                    gst[idx_ / 12][idx_ % 12] = gpre[k];                                     \
-            }                                                                                \
-            __syncthreads();                                                                 \
-            const int y0_ = (uu_ - NSUB) * T;                                                \
-            /* NF independent pixels per lane, computed branch-free so that their LDS reads and */ \
-            /* dependent float chains overlap (one wave per SIMD: nobody else hides them);      */ \
-            /* only the stores are predicated                                                   */ \
-            uint8_t o_[NF];                                                                  \
-            _Pragma("unroll") for (int k = 0; k < NF; k++)                                   \
-            {                                                                                \
-                const int fr_ = min((lane + 64 * k) >> 4, T - 1);                            \
-                const uint8_t *gb_ = reinterpret_cast<const uint8_t *>(&gst[fr_][0]) + 3 * cc; \
-                float q_ = xch[fr_][3][cc];                                                  \
-                q_ = __fadd_rn(q_, __fmul_rn(xch[fr_][0][cc], (float)gb_[0]));               \
-                q_ = __fadd_rn(q_, __fmul_rn(xch[fr_][1][cc], (float)gb_[1]));               \
-                q_ = __fadd_rn(q_, __fmul_rn(xch[fr_][2][cc], (float)gb_[2]));               \
-                o_[k] = saturate_u8(q_);                                                     \
-            }                                                                                \
-            _Pragma("unroll") for (int k = 0; k < NF; k++)                                   \
-            {                                                                                \
-                const int fr_ = (lane + 64 * k) >> 4;                                        \
-                const int y_ = y0_ + fr_, x_ = b * kSB + cc;                                 \
-                if (fr_ < T && y_ < h && x_ < w) {                                           \
-                    const uint32_t pix_ = (uint32_t)y_ * w + x_;                             \
-                    if (SCN == SPX) {                                                        \
-                        dimg[(size_t)pix_ * SCN + s_ch] = o_[k];                             \
-                    } else { /* grey image: the computed channel stands for all three */     \
-                        dimg[(size_t)pix_ * 3 + 0] = o_[k];                                  \
-                        dimg[(size_t)pix_ * 3 + 1] = o_[k];                                  \
-                        dimg[(size_t)pix_ * 3 + 2] = o_[k];                                  \
-                    }                                                                        \
-                }                                                                            \
-            }                                                                                \
-            __syncthreads();                                                                 \
-        }                                                                                    \
-    } while (0)
-
-    RF_ROWTAB(0);
-    __syncthreads();
-    RF_FETCH(0);
-#pragma unroll
-    for (int k = 0; k < NSUB; k++)
-        RF_SUB(k, true, k);
-    for (int u0 = NSUB; u0 < nsub; u0 += NSUB) {
-#pragma unroll
-        for (int k = 0; k < NSUB; k++)
-            if (u0 + k < nsub)
-                RF_SUB(k, false, u0 + k);
-    }
-#undef RF_SUB
-#undef RF_GUIDE_FETCH
-#undef RF_FETCH
-#undef RF_ROWTAB
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1108,6 +691,20 @@ void gf_shutdown()
     g_side_n = 0;
 }
 
+// The per-radius launchers live in the rf_gf_fused_<part>.o units (Makefile: GF_PARTS = 8).
+GfFusedLaunch gf_fused_part_0(int), gf_fused_part_1(int), gf_fused_part_2(int), gf_fused_part_3(int),
+    gf_fused_part_4(int), gf_fused_part_5(int), gf_fused_part_6(int), gf_fused_part_7(int);
+
+GfFusedLaunch gf_fused_launcher(int radius)
+{
+    typedef GfFusedLaunch (*Part)(int);
+    static const Part parts[8] = {gf_fused_part_0, gf_fused_part_1, gf_fused_part_2, gf_fused_part_3,
+                                  gf_fused_part_4, gf_fused_part_5, gf_fused_part_6, gf_fused_part_7};
+    if (radius < 1 || radius > kGfFusedMaxRadius)
+        return nullptr;
+    return parts[(radius - 1) % 8](radius);
+}
+
 size_t gf_workspace_cap()
 {
     static size_t cap = 0;  // the answer cannot change within a process; a benign race at worst
@@ -1187,7 +784,8 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
     // fused stage 2 (row states + column walk) for the instantiated radii; the debug option
     // "gf_two_kernel" forces the row-sum / column-sum kernel pair (cross-check of tests and tools)
     // (the fused kernels index planes with 32-bit element offsets: images below 2^28 pixels)
-    const bool fused = !debug_get(kDbgGfTwoKernel) && (radius == 45 || radius == 52) &&
+    const GfFusedLaunch fused_launch = gf_fused_launcher(radius);
+    const bool fused = !debug_get(kDbgGfTwoKernel) && fused_launch != nullptr &&
                        npx < ((size_t)1 << 28);
     const int nb = ceil_div(w, kSB);
     const size_t per_img_fused = (size_t)np * (npx * sizeof(float) + (size_t)nb * h * sizeof(double));
@@ -1250,31 +848,8 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
             }
             const int row_blocks = ceil_div(h, kBRows);
             if (fused) {
-                if (radius == 45)
-                    hipLaunchKernelGGL((gf_rowstate_kernel<45>), dim3((unsigned)(m * src_cn * row_blocks)),
-                                       dim3(256), 0, st, ab, rows, h, w, row_blocks, np, colour, np, nb);
-                else
-                    hipLaunchKernelGGL((gf_rowstate_kernel<52>), dim3((unsigned)(m * src_cn * row_blocks)),
-                                       dim3(256), 0, st, ab, rows, h, w, row_blocks, np, colour, np, nb);
-                const int it3 = m * 3 * nb, it1 = m * nb;
-                const dim3 g3(8 * (unsigned)ceil_div(it3, 8)), g1(8 * (unsigned)ceil_div(it1, 8));
-#define RF_GF_WALK(R, TT)                                                                             \
-    do {                                                                                           \
-        if (src_cn == 3) {                                                                         \
-            hipLaunchKernelGGL((gf_colwalk_kernel<R, TT, 3, 3>), g3, dim3(64), 0, st, ab, rows, g0, d0, \
-                               h, w, nb, it3, colour);                                             \
-            hipLaunchKernelGGL((gf_colwalk_kernel<R, TT, 1, 3>), g1, dim3(64), 0, st, ab, rows, g0, d0, \
-                               h, w, nb, it1, colour);                                             \
-        } else {                                                                                   \
-            hipLaunchKernelGGL((gf_colwalk_kernel<R, TT, 1, 1>), g1, dim3(64), 0, st, ab, rows, g0, d0, \
-                               h, w, nb, it1, colour);                                             \
-        }                                                                                          \
-    } while (0)
-                if (radius == 45)
-                    RF_GF_WALK(45, 15);
-                else
-                    RF_GF_WALK(52, 13);
-#undef RF_GF_WALK
+                const GfFusedArgs fa = {ab, rows, g0, d0, m, h, w, nb, src_cn, colour, st};
+                fused_launch(fa);
                 continue;
             }
             hipLaunchKernelGGL(gf_rowsum_kernel<4>, dim3((unsigned)(m * np * row_blocks)), dim3(64), 0,

@@ -1,0 +1,643 @@
+// rf_gf_fused.hpp -- fused stage 2 of the guided filter (box means of the alpha/beta planes) for
+// any radius, gfx950.  Included by rf_gf.hip (shared helpers) and by the rf_gf_fused_*.hip units
+// that instantiate the kernels per radius.
+//
+// Contract (opencv/modules/imgproc/src/smooth.cpp boxFilter on CV_32F planes, called 12 times by
+// opencv_contrib/modules/ximgproc/src/guided_filter.cpp; reference call site
+// /root/reference/filter_reflectance.py:67-70): RowSum<float,double> is a running sum along the
+// border-extended row from its left end, ColumnSum<double,float> a running sum down the image
+// from 2r rows above the top.  These float sums are not exact, so the order is part of the
+// contract; both chains are kept sequential and the double row sums never reach HBM:
+//
+//   gf_rowstate_kernel<R>  walks every row of every alpha/beta plane once (one lane per row) and
+//                          stores the running sum only at every 16th column.
+//   gf_colwalk_kernel<R>   one workgroup of TWO waves owns 16 columns x the 4 planes (alpha_0..2,
+//                          beta) of one src channel and walks down the image in sub-tiles of at most
+//                          16 rows; the waves take the sub-tiles alternately.
+//
+// The radius is a template parameter because the value that leaves a running window is the value
+// that entered it 2r (+1) steps earlier IN THE SAME LANE: it is kept in a register FIFO whose slots
+// must be named statically.  The radius-dependent code is small (the FIFO steps); the kernels are
+// instantiated for every radius 1..kGfFusedMaxRadius and picked by a table (rf_gf_fused_*.hip).
+#pragma once
+#include "rf_common.hpp"
+
+#include <type_traits>
+
+namespace rf {
+
+constexpr int kGfFusedMaxRadius = 96;
+constexpr int kSB = 16;     // columns per state block and per column-walk workgroup
+constexpr int kBRows = 64;  // rows per row-walk workgroup (one lane per row)
+
+// Does this workgroup's instantiation apply to image img?  (colour == nullptr: no choice to make)
+template <int SCN>
+__device__ inline bool wrong_variant(const int *__restrict__ colour, int img)
+{
+    return colour != nullptr && (colour[img] != 0) != (SCN == 3);
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// Orders the LDS traffic of ONE wave: the LDS executes a wave's instructions in issue order, so a
+// later read of another lane's earlier write needs no barrier, only that the compiler keeps the
+// order and that the data has landed before it is used (lgkmcnt).  Global loads stay in flight.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ------------------------------------------------------------------------------------------
+// Row walk.  planes: [img][src_np / 4][h][w][4] (the four planes of a src channel interleaved per
+// pixel); states: [img * np + plane][nb][h], nb = ceil(w / 16); states[..][b][row] = RowSum at
+// column 16 b.  grid: (plane groups of the chunk) x (64-row blocks); one workgroup = 4 waves = the
+// 4 planes of a group, lane = row, walking the border-extended row ext[i] = S[bi(i - r)] from its
+// left end.  The workgroup fetches a chunk of 16 columns x 64 rows as float4 pixels (256
+// contiguous bytes per image row and load) and hands each wave its plane through LDS (20 KB).  The
+// value leaving the window, ext[i - ks], is kept in a register FIFO of F >= ks floats, F a
+// multiple of 16 (slot = step mod F, static because the loop body is one period of F steps, fully
+// unrolled).  The stream is prefixed with PAD dummy steps so that every chunk of 16 steps is an
+// aligned run of 16 source columns.  A workgroup walks its rows alone from end to end, so the time
+// of the kernel is the time of a chunk: two chunks of loads are in flight (buffers A and B
+// alternate by chunk), and a full chunk forms its 16 operand differences before the chain of
+// dependent adds (one LDS round trip per chunk, not per step).
+// ------------------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(256) void gf_rowstate_kernel(const float *__restrict__ planes,
+                                                          double *__restrict__ states, int h, int w,
+                                                          int row_blocks, int np,
+                                                          const int *__restrict__ colour, int src_np,
+                                                          int nb)
+{
+    constexpr int KS = 2 * R + 1;
+    constexpr int F = (KS + 15) & ~15;
+    constexpr int NCH = F / 16;
+    constexpr int PAD = (16 - R % 16) % 16;  // step t <-> extended index i = t - PAD, column i - R
+    constexpr int NPER = (NCH & 1) ? 2 : 1;  // periods per loop body: the buffers swap roles from
+                                             // one period to the next when NCH is odd
+    static_assert(KS + PAD <= 2 * F, "the window fills within the two peeled periods");
+    const int ng = np / 4;                     // plane groups (src channels) per image
+    const int grp = blockIdx.x / row_blocks;   // plane group across the chunk of images
+    const int img = grp / ng, gq = grp - img * ng;
+    if (colour != nullptr && gq >= 1 && colour[img] == 0)
+        return;  // grey 3-channel images only carry the 4 planes of their first channel
+    __shared__ __align__(16) float tE[4][kBRows][20];  // pitch 20: 16-byte rows, conflict-free
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // the wave's plane of the group
+    const int row0 = (blockIdx.x - grp * row_blocks) * kBRows;
+    const float4 *S4 =
+        reinterpret_cast<const float4 *>(planes + ((size_t)img * src_np + gq * 4) * h * w);
+    double *ST = states + ((size_t)img * np + gq * 4 + wv) * nb * h + row0 + lane;
+    const int total = w + 2 * R + PAD;  // steps
+    // loader role: the workgroup fetches the chunk's 64 rows x 16 columns as 1024 float4 (all
+    // four planes of a pixel), thread t the pixels t, t + 256, ...: 16 consecutive threads read
+    // 256 contiguous bytes of one image row
+    const int cc = tid & 15;
+    const bool row_ok = row0 + lane < h;
+    uint32_t srow[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        srow[k] = (uint32_t)min(row0 + ((tid + 256 * k) >> 4), h - 1) * (uint32_t)w;
+
+    float4 preA[4], preB[4];
+    // (a chunk away from both ends of the row needs no border arithmetic; pixel offsets fit 32
+    //  bits - the host admits images below 2^28 pixels here - so a load is SGPR base + byte offset)
+    auto fetch = [&](int t0, float4(&buf)[4]) __attribute__((always_inline)) {
+        const int x0 = t0 - PAD - R;
+        int sx = x0 + cc;
+        if (x0 < 0 || x0 + 15 >= w || t0 + 15 >= total)
+            sx = border_interpolate(min(t0 + cc, total - 1) - PAD - R, w, RF_BORDER_REFLECT);
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            buf[k] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(S4) +
+                                                       ((srow[k] + (uint32_t)sx) << 4));
+    };
+    double s = 0.0;
+    float fifo[F];
+    // one chunk of 16 steps; PER = period (0, 1: peeled, window still filling; 2: steady state),
+    // KCH = chunk of the period: step t = t0 + c with (t mod F) = KCH*16 + c static
+    auto chunk = [&](auto per_c, auto kch_c, int t0, float4(&buf)[4]) __attribute__((always_inline)) {
+        constexpr int PER = decltype(per_c)::value, KCH = decltype(kch_c)::value;
+        if (t0 >= total)
+            return;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int r_ = (tid + 256 * k) >> 4;
+            tE[0][r_][cc] = buf[k].x;
+            tE[1][r_][cc] = buf[k].y;
+            tE[2][r_][cc] = buf[k].z;
+            tE[3][r_][cc] = buf[k].w;
+        }
+        __syncthreads();
+        if (t0 + 32 < total)
+            fetch(t0 + 32, buf);
+        if (PER == 2 && KS >= 16 && t0 + 16 <= total) {
+            // full chunk in the steady state: the 16 operands first (16-byte LDS reads), the
+            // differences against the FIFO (every value that leaves during the chunk entered in
+            // an earlier chunk because ks >= 16; radii below 8 take the step-by-step path), then
+            // the dependent adds: one LDS round trip per chunk, no per-step branch
+            float4 e4[4];
+#pragma unroll
+            for (int c4 = 0; c4 < 4; c4++)
+                e4[c4] = *reinterpret_cast<const float4 *>(&tE[wv][lane][4 * c4]);
+            const float e[16] = {e4[0].x, e4[0].y, e4[0].z, e4[0].w, e4[1].x, e4[1].y,
+                                 e4[1].z, e4[1].w, e4[2].x, e4[2].y, e4[2].z, e4[2].w,
+                                 e4[3].x, e4[3].y, e4[3].z, e4[3].w};
+#pragma unroll
+            for (int hh = 0; hh < 2; hh++) {
+                double d[8];
+#pragma unroll
+                for (int c8 = 0; c8 < 8; c8++)
+                    d[c8] = (double)e[8 * hh + c8] -
+                            (double)fifo[(KCH * 16 + 8 * hh + c8 + F - (KS % F)) % F];
+#pragma unroll
+                for (int c8 = 0; c8 < 8; c8++) {
+                    const int c = 8 * hh + c8;
+                    s += d[c8];
+                    if (((c - PAD - KS + 1) & (kSB - 1)) == 0 && row_ok)
+                        ST[(size_t)((t0 + c - PAD - KS + 1) >> 4) * h] = s;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 16; c++)
+                fifo[KCH * 16 + c] = e[c];
+        } else {
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+                const int tp = KCH * 16 + c;         // t mod F
+                const int ip = PER * F + tp - PAD;    // i (exact in the peeled periods)
+                if (PER < 2 && ip < 0) {
+                    // dummy step in front of the row
+                } else if (t0 + c < total) {
+                    const float e = tE[wv][lane][c];
+                    if (PER < 2 && ip < KS)
+                        s += (double)e;
+                    else
+                        s += (double)e - (double)fifo[(tp + F - (KS % F)) % F];
+                    fifo[tp] = e;
+                    const int o = t0 + c - PAD - KS + 1;  // output column of this RowSum
+                    if (o >= 0 && (o & (kSB - 1)) == 0 && row_ok)
+                        ST[(size_t)(o >> 4) * h] = s;
+                }
+            }
+        }
+    };
+    // one period of NCH chunks starting at step t0; PARITY = parity of its first chunk (buffer A
+    // serves the even chunks of the row, B the odd ones)
+    auto period = [&](auto per_c, auto parity_c, int t0) __attribute__((always_inline)) {
+        constexpr int PARITY = decltype(parity_c)::value;
+        static_for<0, NCH>([&](auto k) __attribute__((always_inline)) {
+            constexpr int K = decltype(k)::value;
+            if constexpr (((K + PARITY) & 1) == 0)
+                chunk(per_c, k, t0 + 16 * K, preA);
+            else
+                chunk(per_c, k, t0 + 16 * K, preB);
+        });
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    fetch(0, preA);
+    fetch(16, preB);
+    period(I0{}, I0{}, 0);
+    period(I1{}, std::integral_constant<int, NCH & 1>{}, F);
+    for (int t0 = 2 * F; t0 < total; t0 += NPER * F) {
+        period(I2{}, I0{}, t0);  // 2 NCH chunks precede: even parity again
+        if constexpr (NPER == 2)
+            period(I2{}, I1{}, t0 + F);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Column walk.
+//
+// Geometry of the walk for radius R.  The image rows are padded to i = 0 .. h + 2R - 1 (padded row
+// i <-> image row bi(i - R)).  A period of 2R padded rows is cut into 2M sub-tiles, M = ceil(R/16)
+// per half period, of T or T - 1 rows each (T = ceil(R/M) <= 16; both halves are cut alike).  The
+// two waves of a workgroup take the sub-tiles alternately (wave = sub-tile index mod 2).  A value
+// that enters the column window in sub-tile j leaves it exactly one period (2M sub-tiles, an even
+// number) later, i.e. in a sub-tile OF THE SAME WAVE at the same position: each wave keeps only its
+// own half of the 2R-deep FIFO in registers (R doubles, +-1), all slots static.
+// ------------------------------------------------------------------------------------------
+template <int R>
+struct WalkGeom {
+    static constexpr int M = (R + 15) / 16;
+    static constexpr int T = (R + M - 1) / M;
+    static constexpr int BIG = R - M * (T - 1);  // the first BIG sub-tiles of a half have T rows
+    static_assert(R >= 1 && T >= 1 && T <= 16 && BIG >= 1 && BIG <= M, "walk geometry");
+    // c = position in the period, 0 .. 2M-1
+    __host__ __device__ static constexpr int size(int c) { return (c % M) < BIG ? T : T - 1; }
+    __host__ __device__ static constexpr int start(int c)
+    {
+        const int p = c % M;
+        return (c >= M ? R : 0) + p * (T - 1) + (p < BIG ? p : BIG);
+    }
+    // first FIFO slot of position c in its wave's FIFO
+    __host__ __device__ static constexpr int fifo_off(int c)
+    {
+        int o = 0;
+        for (int k = c & 1; k < c; k += 2)
+            o += size(k);
+        return o;
+    }
+    __host__ __device__ static constexpr int fifo_len()
+    {
+        int a = 0, b = 0;
+        for (int k = 0; k < 2 * M; k += 2)
+            a += size(k);
+        for (int k = 1; k < 2 * M; k += 2)
+            b += size(k);
+        return a > b ? a : b;
+    }
+};
+
+// Diagnostic build only (-DRF_GF_STAMP, tools/gf_stamp_build.py): per-phase shader cycles of the
+// column walk, summed over waves, in a buffer of their own; no output depends on them.
+#ifdef RF_GF_STAMP
+__device__ unsigned long long g_cw_stamps[16];
+#define RF_STAMP(i)                                                     \
+    do {                                                                \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();   \
+        st_acc[i] += now_ - st_t;                                       \
+        st_t = now_;                                                    \
+    } while (0)
+#else
+#define RF_STAMP(i) do { } while (0)
+#endif
+
+template <int T>
+struct alignas(16) WalkLds {
+    static constexpr int TP = T | 1;  // odd pitch: 64-bit column reads are conflict-free
+    double Rt[64][TP];                // row sums [plane*16 + col][row]
+    union {
+        struct {
+            float E[4 * T][kSB + 1], L[4 * T][kSB + 1];  // operands [plane*T + row][col]
+        } st;
+        float xch[T][80];  // means of the sub-tile's rows [row][plane*16 + col] (pitch 80: the
+                           // four rows a flush instruction reads sit on different banks)
+    } u;
+    int rowtab[2][T + 1];     // image row of each padded row
+    uint32_t rowoff[2][T + 1];  // ... times 16 w (byte offset of the row in a plane group)
+};
+
+// grid: 8 * ceil(pairs / 8) * spx workgroups of two waves; pairs = images x nb column blocks, walked
+// so that each XCD (workgroup id mod 8) owns a contiguous run of column blocks: a block's "leaving"
+// operands are the "entering" operands of the block ~(2r+1)/16 places to its left.
+//   row phase     lane = (plane, row): 4 x T chains of 15 steps from the stored states -> Rt (LDS)
+//   column phase  lane = (plane, column): up to T steps of ColumnSum<double,float>; the running
+//                 SUM passes from wave to wave through LDS (sumx, turn)
+//   flush         the finished pixels: q = beta + a0 I0 + a1 I1 + a2 I2 -> uint8
+// Each wave requests the operands and states of its next sub-tile before the chains of the current
+// one run; nothing but the SUM hand-off couples the two waves, so one wave's loads, row chains and
+// flush overlap the other's (two waves per SIMD up to radius ~64).
+// Vector-memory instructions are the scarce resource of this kernel (a sub-tile of dword loads and
+// byte stores spent 4 of its 9 thousand cycles issuing them): operands are fetched as float4 pixels,
+// four image rows per instruction (lane = row of the group x column), the guide bytes of a lane's
+// four output pixels come as one 12-byte load straight into registers, and a lane stores its four
+// pixels with one instruction where the layout allows (12 bytes for a grey 3-channel image, 4 for a
+// 1-channel one) - 11 to 14 vector-memory instructions per sub-tile instead of 46.
+// spx = src bytes per pixel (1 or 3).  With spx = 3 an image whose flag colour[img] is 0 has three
+// equal channels: only its channel 0 is computed and the result byte is written three times.
+template <int R>
+__global__ __launch_bounds__(128, (R <= 64 ? 2 : 1)) void gf_colwalk_kernel(
+    const float *__restrict__ ab, const double *__restrict__ states,
+    const uint8_t *__restrict__ guide, uint8_t *__restrict__ dst, int h, int w, int nb,
+    int n_pairs, int spx, const int *__restrict__ colour)
+{
+    using G = WalkGeom<R>;
+    constexpr int M = G::M, T = G::T;
+    constexpr int KS = 2 * R + 1;
+    constexpr int FL = G::fifo_len();
+    constexpr int NL = (T + 3) / 4;  // operand load instructions per sub-tile and side (4 rows each)
+    // work item = (image, column block) pair x src channel.  Workgroups are dealt round-robin to
+    // the 8 XCDs, so workgroup id -> (XCD, index on it); every XCD owns a contiguous run of pairs
+    // and walks pair by pair through the channels: the channels of a block share their guide rows
+    // in that XCD's L2, and the channel items of grey 3-channel images that exit at once are spread
+    // evenly over the XCDs
+    const int per_xcd = (n_pairs + 7) >> 3;
+    const int q = (int)(blockIdx.x >> 3);
+    const int pair = (int)(blockIdx.x & 7) * per_xcd + q / spx;
+    if (q / spx >= per_xcd || pair >= n_pairs)
+        return;
+    const int s_ch = q % spx;
+    const int b = pair % nb;
+    const int img = pair / nb;
+    const bool grey3 = spx == 3 && colour[img] == 0;  // three equal channels: channel 0 stands for all
+    if (grey3 && s_ch > 0)
+        return;
+
+    __shared__ WalkLds<T> lds[2];
+    __shared__ double sumx[64];
+    __shared__ int turn;  // next sub-tile whose column phase may run
+
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    WalkLds<T> &L = lds[wv];
+    if (threadIdx.x == 0)
+        turn = 0;
+    __syncthreads();  // the only barrier: both waves see turn = 0
+
+    const int cc = lane & 15;                    // column role: lane = plane * 16 + column
+    const int cp = lane / T, cl = lane - cp * T;  // chain role (lane < 4T): plane, row
+    const bool chain = lane < 4 * T;
+    const size_t npx = (size_t)h * w;
+    const int np = 4 * spx;
+    const float *abg = ab + ((size_t)img * np + 4 * s_ch) * npx;          // planes 4s .. 4s+3
+    const double *stg = states + ((size_t)img * np + 4 * s_ch) * nb * h;  // their states
+    const uint8_t *gimg = guide + (size_t)img * npx * 3;
+    uint8_t *dimg = dst + (size_t)img * npx * spx;
+    // RowSum at output column o = 16 b + cc (cc >= 1):  + ext[o + 2r] - ext[o - 1], ext[i] = S[bi(i - r)]
+    // per-lane BYTE offsets of the float4 pixel from the wave-uniform base abg of the channel's
+    // plane group ([h][w][4] floats; 32 bits: the host admits images below 2^28 pixels here)
+    const uint32_t oe = 16u * (uint32_t)border_interpolate(b * kSB + cc + R, w, RF_BORDER_REFLECT);
+    const uint32_t ol =
+        16u * (uint32_t)border_interpolate(b * kSB + cc - 1 - R, w, RF_BORDER_REFLECT);
+    const char *abgb = reinterpret_cast<const char *>(abg);
+    const double *Ps = stg + ((size_t)min(cp, 3) * nb + b) * h;
+    const double scale = 1.0 / (double)(KS * KS);
+    const int total = h + 2 * R;  // padded rows
+    const int jmax = total - 1;
+    int nsub;                     // sub-tiles that start inside the padded image
+    {
+        const int full = total / (2 * R), rem = total - full * 2 * R;
+        int cnt = 0;
+#pragma unroll
+        for (int c = 0; c < 2 * M; c++)
+            cnt += G::start(c) < rem ? 1 : 0;
+        nsub = full * 2 * M + cnt;
+    }
+    const uint32_t gbytes = (uint32_t)(npx * 3);
+
+    const int r4 = lane >> 4;            // loader role: row of a group of four, column cc
+    const int fr = lane >> 2, qd = lane & 3;  // flush role: row of the sub-tile, quad of columns
+    float4 pe[NL], pl[NL];
+    double pst = 0.0;
+    uint32_t gpre[3];  // guide bytes of the lane's four output pixels
+    double SUM = 0.0;
+    double fifo[FL];
+
+    // padded row -> image row (BORDER_REFLECT) of the sub-tile starting at padded row i0
+    auto rowtab = [&](int slot, int i0) __attribute__((always_inline)) {
+        if (lane < T) {
+            const int row = border_interpolate(min(i0 + lane, jmax) - R, h, RF_BORDER_REFLECT);
+            L.rowtab[slot][lane] = row;
+            L.rowoff[slot][lane] = 16u * (uint32_t)row * (uint32_t)w;
+        }
+    };
+    auto fetch = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            const uint32_t ro = L.rowoff[slot][min(4 * i + r4, T - 1)];
+            pe[i] = *reinterpret_cast<const float4 *>(abgb + (oe + ro));
+            pl[i] = *reinterpret_cast<const float4 *>(abgb + (ol + ro));
+        }
+        if (chain)
+            pst = Ps[L.rowtab[slot][cl]];
+    };
+    // guide bytes of the lane's output pixels: row y0 + fr, columns 16 b + 4 qd .. + 3 (12 bytes)
+    auto guide_fetch = [&](int y0) __attribute__((always_inline)) {
+        const int gy = min(y0 + fr, h - 1);
+        const uint32_t off = ((uint32_t)gy * w + b * kSB + 4 * qd) * 3;
+        gpre[0] = gpre[1] = gpre[2] = 0;
+        if (off + 12 <= gbytes) {
+            __builtin_memcpy(gpre, gimg + off, 12);
+        } else {  // the last bytes of the image (or columns past its right edge)
+            for (int q = 0; q < 12; q++)
+                if (off + q < gbytes)
+                    gpre[q >> 2] |= (uint32_t)gimg[off + q] << (8 * (q & 3));
+        }
+    };
+
+    // position of this wave's current sub-tile: j = index, jp = j mod 2M, pbase = first padded row
+    // of its period
+    int j = wv, jp = wv % (2 * M), pbase = (wv / (2 * M)) * 2 * R;
+    auto advance = [&](int &jj, int &jjp, int &pb) __attribute__((always_inline)) {
+        jj += 2;
+        jjp += 2;
+        if (jjp >= 2 * M) {
+            jjp -= 2 * M;
+            pb += 2 * R;
+        }
+    };
+
+    // the finished pixels of the previous sub-tile: their stores are issued at the top of the NEXT
+    // iteration, after the wait for its operands - vmcnt retires in order, so stores issued last in
+    // an iteration would put their whole latency in front of that wait
+    uint32_t o4 = 0;           // the lane's four result bytes (columns 16 b + 4 qd .. + 3 of row fr)
+    int st_y0 = 0, st_tj = 0;  // pending stores: rows st_y0 .. st_y0 + st_tj - 1 (st_tj = 0: none)
+    auto store_pending = [&]() __attribute__((always_inline)) {
+        const int y = st_y0 + fr, x = b * kSB + 4 * qd;
+        if (fr >= st_tj || y >= h || x >= w)
+            return;
+        const uint32_t pix = (uint32_t)y * w + x;
+        if (x + 3 < w && (grey3 || spx == 1)) {
+            if (grey3) {  // every result byte three times: 12 contiguous bytes
+                const uint32_t b0 = o4 & 0xff, b1 = (o4 >> 8) & 0xff, b2 = (o4 >> 16) & 0xff,
+                               b3 = o4 >> 24;
+                const uint32_t d[3] = {b0 * 0x010101u | (b1 << 24), b1 * 0x0101u | (b2 * 0x0101u << 16),
+                                       b2 | (b3 * 0x010101u << 8)};
+                __builtin_memcpy(dimg + (size_t)pix * 3, d, 12);
+            } else {
+                __builtin_memcpy(dimg + pix, &o4, 4);
+            }
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (x + i >= w)
+                break;
+            const uint8_t v = (uint8_t)(o4 >> (8 * i));
+            if (grey3) {
+                dimg[(size_t)(pix + i) * 3 + 0] = v;
+                dimg[(size_t)(pix + i) * 3 + 1] = v;
+                dimg[(size_t)(pix + i) * 3 + 2] = v;
+            } else {
+                dimg[(size_t)(pix + i) * spx + s_ch] = v;
+            }
+        }
+    };
+#ifdef RF_GF_STAMP
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_t = __builtin_amdgcn_s_memtime();
+    unsigned long long st_n = 0;
+#endif
+
+    if (j < nsub) {
+        rowtab(0, pbase + G::start(jp));
+        wave_lds_fence();
+        fetch(0);
+    }
+    int slot = 0;
+    for (; j < nsub;) {
+        const int i0 = pbase + G::start(jp);
+        const int tj = G::size(jp);
+        const bool fill = j < 2 * M;  // first period: padded rows 0 .. 2R-1 only fill the window
+        int jn = j, jpn = jp, pbn = pbase;
+        advance(jn, jpn, pbn);
+        rowtab(slot ^ 1, pbn + G::start(jpn));
+        RF_STAMP(0);
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            const int r = 4 * i + r4;  // row of the sub-tile this lane fetched (rows >= T: repeats)
+            if (4 * i + 3 < T || r < T) {
+                L.u.st.E[r][cc] = pe[i].x;
+                L.u.st.E[T + r][cc] = pe[i].y;
+                L.u.st.E[2 * T + r][cc] = pe[i].z;
+                L.u.st.E[3 * T + r][cc] = pe[i].w;
+                L.u.st.L[r][cc] = pl[i].x;
+                L.u.st.L[T + r][cc] = pl[i].y;
+                L.u.st.L[2 * T + r][cc] = pl[i].z;
+                L.u.st.L[3 * T + r][cc] = pl[i].w;
+            }
+        }
+        double s = pst;
+        RF_STAMP(1);  // wait for the operands (and every older store)
+        store_pending();
+        st_tj = 0;
+        wave_lds_fence();
+        if (!fill)
+            guide_fetch(i0 - 2 * R);
+        if (jn < nsub)
+            fetch(slot ^ 1);
+        RF_STAMP(2);
+        if (chain) {
+            // all operand differences first (independent LDS reads and conversions), then the
+            // chain of dependent adds
+            double d[kSB];
+#pragma unroll
+            for (int c = 1; c < kSB; c++)
+                d[c] = (double)L.u.st.E[lane][c] - (double)L.u.st.L[lane][c];
+            L.Rt[cp * kSB][cl] = s;
+#pragma unroll
+            for (int c = 1; c < kSB; c++) {
+                s += d[c];
+                L.Rt[cp * kSB + c][cl] = s;
+            }
+        }
+        wave_lds_fence();
+        RF_STAMP(3);
+        // --- column phase: wait for the SUM of sub-tile j - 1 (the other wave's)
+        if (j > 0) {
+            while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(
+                       &turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < j)
+                __builtin_amdgcn_s_sleep(1);
+            wave_lds_fence();
+            SUM = __hip_atomic_load(&sumx[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        RF_STAMP(4);
+        static_for<0, 2 * M>([&](auto cpos) __attribute__((always_inline)) {
+            constexpr int C = decltype(cpos)::value;
+            constexpr int TJ = G::size(C), OFF = G::fifo_off(C);
+            if (jp == C) {
+                double v[TJ];
+#pragma unroll
+                for (int q = 0; q < TJ; q++)
+                    v[q] = L.Rt[lane][q];
+                if (fill) {
+#pragma unroll
+                    for (int q = 0; q < TJ; q++) {
+                        SUM += v[q];
+                        fifo[OFF + q] = v[q];
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < TJ; q++) {
+                        const double s0 = SUM + v[q];
+                        L.u.xch[q][lane] = (float)(s0 * scale);
+                        SUM = s0 - fifo[OFF + q];
+                        fifo[OFF + q] = v[q];
+                    }
+                }
+            }
+        });
+        __hip_atomic_store(&sumx[lane], SUM, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        wave_lds_fence();
+        if (lane == 0)
+            __hip_atomic_store(&turn, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        RF_STAMP(5);
+        // --- flush: the bytes of the finished pixels (stored at the top of the next iteration)
+        if (!fill) {
+            // the lane's four pixels: means as 16-byte LDS reads, guide bytes from registers
+            const int frc = min(fr, T - 1);
+            const float4 a0 = *reinterpret_cast<const float4 *>(&L.u.xch[frc][4 * qd]);
+            const float4 a1 = *reinterpret_cast<const float4 *>(&L.u.xch[frc][16 + 4 * qd]);
+            const float4 a2 = *reinterpret_cast<const float4 *>(&L.u.xch[frc][32 + 4 * qd]);
+            const float4 bt = *reinterpret_cast<const float4 *>(&L.u.xch[frc][48 + 4 * qd]);
+            const float A0[4] = {a0.x, a0.y, a0.z, a0.w}, A1[4] = {a1.x, a1.y, a1.z, a1.w};
+            const float A2[4] = {a2.x, a2.y, a2.z, a2.w}, BT[4] = {bt.x, bt.y, bt.z, bt.w};
+            o4 = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float i0g = (float)((gpre[(3 * i) >> 2] >> (8 * ((3 * i) & 3))) & 0xff);
+                const float i1g = (float)((gpre[(3 * i + 1) >> 2] >> (8 * ((3 * i + 1) & 3))) & 0xff);
+                const float i2g = (float)((gpre[(3 * i + 2) >> 2] >> (8 * ((3 * i + 2) & 3))) & 0xff);
+                float q = BT[i];
+                q = __fadd_rn(q, __fmul_rn(A0[i], i0g));
+                q = __fadd_rn(q, __fmul_rn(A1[i], i1g));
+                q = __fadd_rn(q, __fmul_rn(A2[i], i2g));
+                o4 |= (uint32_t)saturate_u8(q) << (8 * i);
+            }
+            st_y0 = i0 - 2 * R;
+            st_tj = tj;
+            wave_lds_fence();
+        }
+        RF_STAMP(6);
+#ifdef RF_GF_STAMP
+        st_n++;
+#endif
+        j = jn;
+        jp = jpn;
+        pbase = pbn;
+        slot ^= 1;
+    }
+    store_pending();
+#ifdef RF_GF_STAMP
+    if (lane == 0) {
+        for (int i = 0; i < 7; i++)
+            atomicAdd(&g_cw_stamps[i], st_acc[i]);
+        atomicAdd(&g_cw_stamps[15], st_n);
+    }
+#endif
+}
+
+// Launches of the fused stage 2 for one radius (defined per radius in rf_gf_fused_*.hip).
+struct GfFusedArgs {
+    const float *ab;
+    double *states;
+    const uint8_t *guide;
+    uint8_t *dst;
+    int m, h, w, nb, src_cn;
+    const int *colour;
+    hipStream_t stream;
+};
+typedef void (*GfFusedLaunch)(const GfFusedArgs &);
+GfFusedLaunch gf_fused_launcher(int radius);  // nullptr outside 1 .. kGfFusedMaxRadius
+
+template <int R>
+void gf_fused_launch(const GfFusedArgs &a)
+{
+    const int row_blocks = (a.h + kBRows - 1) / kBRows;
+    const int np = 4 * a.src_cn;
+    hipLaunchKernelGGL((gf_rowstate_kernel<R>), dim3((unsigned)(a.m * a.src_cn * row_blocks)),
+                       dim3(256), 0, a.stream, a.ab, a.states, a.h, a.w, row_blocks, np, a.colour,
+                       np, a.nb);
+    const int pairs = a.m * a.nb;
+    hipLaunchKernelGGL((gf_colwalk_kernel<R>), dim3(8u * (unsigned)((pairs + 7) / 8) * a.src_cn),
+                       dim3(128), 0, a.stream, a.ab, a.states, a.guide, a.dst, a.h, a.w, a.nb, pairs,
+                       a.src_cn, a.colour);
+}
+
+}  // namespace rf

@@ -811,6 +811,38 @@ def test_two_streams_do_not_share_scratch(env):
         assert torch.equal(r1, want_r1) and torch.equal(r2, want_r2)
 
 
+@pytest.mark.parametrize("radius", [1, 2, 5, 7, 8, 13, 16, 17, 20, 30, 33, 47, 60, 64, 65, 77, 96, 97])
+def test_gf_fused_stage2_any_radius(env, radius):
+    """The fused stage 2 is instantiated for every radius 1..96 (97: the row-sum / column-sum pair):
+    sub-tiles of unequal height (47 = 16 + 16 + 15), one sub-tile per half period (radius < 16),
+    the step-by-step row walk of radii below 8, one wave per SIMD above 64 - against the oracle
+    (grey, colour and 1-channel src; two chained passes) and against the two-kernel form on a
+    shape with partial column blocks and fewer rows than the radius."""
+    from tests import synth
+    rf, co, torch = env
+    eps = 3.0 if radius % 2 else 7.0
+    h, w = 70, 83
+    guide = synth.flat_guide_u8(h, w, seed=radius, cells=9)
+    colour = synth.scene_u8(h, w, seed=radius + 1)
+    grey = synth.reflectance_like_u8(h, w, seed=radius + 2)
+    g = torch.from_numpy(np.stack([guide, guide])).cuda()
+    s = torch.from_numpy(np.stack([colour, grey])).cuda()      # one colour, one grey image
+    got = rf.ops.guided_filter_u8(g, s, radius, eps, iterations=2).cpu().numpy()
+    for i, src in enumerate((colour, grey)):
+        want = co.guided_filter(guide, co.guided_filter(guide, src, radius, eps), radius, eps)
+        assert np.array_equal(got[i], want), (radius, i)
+    one = torch.from_numpy(grey[None, :, :, :1].copy()).cuda()
+    got1 = rf.ops.guided_filter_u8(g[:1], one, radius, eps).cpu().numpy()[0]
+    assert np.array_equal(got1, co.guided_filter(guide, grey[:, :, :1].copy(), radius, eps).reshape(got1.shape))
+    for hh, ww in ((radius // 2 + 1, 130), (150, 2 * radius + 19)):
+        gg = torch.from_numpy(synth.scene_u8(hh, ww, seed=3)[None]).cuda()
+        ss = torch.from_numpy(synth.scene_u8(hh, ww, seed=4)[None]).cuda()
+        a = rf.ops.guided_filter_u8(gg, ss, radius, eps, iterations=3)
+        with rf._ffi.debug_options(gf_two_kernel=1):
+            b = rf.ops.guided_filter_u8(gg, ss, radius, eps, iterations=3)
+        assert torch.equal(a, b), (radius, hh, ww)
+
+
 @pytest.mark.parametrize("radius,eps", [(45, 3.0), (52, 7.0)])
 def test_gf_fused_stage2_in_place_chain_and_oracle(env, radius, eps):
     """The fused stage 2 (radius 45 / 52): colour and grey images in one batch, three chained

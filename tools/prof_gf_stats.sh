@@ -1,12 +1,16 @@
 #!/bin/bash
 # Quick per-kernel timing of one guided-filter pass (8 x 4K, grey and colour src):
-#   tools/prof_gf_stats.sh   (through gpurun, from the repo root; prints avg ns per kernel)
+#   tools/prof_gf_stats.sh [radius] [lib] [batch]  (through gpurun, from the repo root; prints avg us per
+#   kernel, the batch on ONE stream so that the durations are those of kernels running alone)
 set -u
 export TMPDIR=/tmp
-O=gpurun_out/gfstats
+RAD=${1:-45}
+LIB=${2:-reflectance_filtering_amd/librf_hip.so}
+NB=${3:-8}
+O=gpurun_out/gfstats_$(basename $LIB)_r$RAD
 rm -rf $O; mkdir -p $O
 for kind in grey colour; do
-    rocprofv3 --kernel-trace --stats --output-format csv -d $O/$kind -- python3 tools/gf_profile.py 8 2160 3840 $kind > $O/$kind.log 2>&1
+    rocprofv3 --kernel-trace --stats --output-format csv -d $O/$kind -- python3 tools/gf_profile.py $NB 2160 3840 $kind 1 nowall one $RAD $LIB > $O/$kind.log 2>&1
     f=$(find $O/$kind -name "*kernel_stats.csv" | head -1)
     echo "== $kind"
     python3 - "$f" <<'PY'
