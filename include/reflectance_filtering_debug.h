@@ -19,6 +19,8 @@
  *   "gf_one_stream"      guided filter: the whole batch on the caller's stream (the default runs
  *                        the two halves of a batch on the caller's stream and on a side stream of
  *                        the library, forked / joined with events inside the call); identical bytes
+ *   "gf_force_two_streams"  guided filter: fork the side stream for every chunk of two or more
+ *                        images (the default decides by batch size and src kind); identical bytes
  *   "jbf_stage_only"     joint bilateral: stage the tile and return WITHOUT WRITING dst
  *                        (tools/jbf_tune.py --stage-only, timing only)
  */

@@ -82,6 +82,7 @@ enum DebugOption {
     kDbgCnnLdsColumns,     // CNN: activations handed between layers through LDS columns (round-1 form)
     kDbgGfSegRows,         // guided filter: rows per stage-1 segment (0 = chosen by the library)
     kDbgGfOneStream,       // guided filter: the whole chunk on the caller's stream (no side stream)
+    kDbgGfForceTwoStreams, // guided filter: fork the side stream for any chunk of two or more images
     kDbgCount
 };
 int debug_get(int id);

@@ -867,22 +867,25 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
         }
     };
 
-    // A chunk of two or more images runs as two halves on two streams - the caller's and a side
+    // A chunk of eight or more images runs as two halves on two streams - the caller's and a side
     // stream of the library, forked and joined with events, so the call still looks stream-ordered
     // to the caller and can be captured into a graph.  The kernels of a pass are bound by different
-    // things (stage 1: latency at 3-4 waves per SIMD; row states: the latency of a chunk; column
-    // walk: the issue rate of its one wave per SIMD, which leaves half of a SIMD's registers
-    // free), and every launch ends in a tail of partly filled CUs: the other half's kernels fill
-    // both.  Measured (3 passes at 4K): 8 images grey 6.13 -> 6.08 ms, colour 14.0 -> 12.2 ms; 13
-    // images grey 10.8 -> 9.4 ms, colour 24.1 -> 19.9 ms.  The debug option "gf_one_stream" keeps
-    // everything on the caller's stream (cross-check; identical bytes).
+    // things (stage 1: the issue rate of its 4-cycle VALU instructions; row states: the latency of
+    // a chunk of loads; column walk: memory bandwidth), and every launch ends in a tail of partly
+    // filled CUs: the other half's kernels fill both.  The debug option "gf_one_stream" keeps
+    // everything on the caller's stream, "gf_force_two_streams" forks from two images on
+    // (cross-checks; identical bytes).
     char *ws0 = static_cast<char *>(workspace) + header;
     hipStream_t side = nullptr;
-    if (fused && chunk >= 2 && !debug_get(kDbgGfOneStream))
+    // (tools/gf_stream_sweep.py, 3 passes at 4K, two streams over one: grey 1.10 / 1.18 / 1.00 /
+    //  0.93 / 0.92 / 0.87 / 0.91 and colour 0.99 / 0.97 / 0.91 / 0.93 / 0.91 / 0.89 / 0.89 at 2 / 4 /
+    //  8 / 12 / 16 / 24 / 36 images: small grey launches leave XCDs idle when halved)
+    const int fork_from = debug_get(kDbgGfForceTwoStreams) ? 2 : 8;
+    if (fused && chunk >= fork_from && !debug_get(kDbgGfOneStream))
         side = gf_side_stream(stream);
     for (int i0 = 0; i0 < n; i0 += chunk) {
         const int m = std::min(chunk, n - i0);
-        if (side == nullptr || m < 2) {
+        if (side == nullptr || m < fork_from) {
             run_part(i0, m, m, ws0, stream);
             continue;
         }

@@ -647,11 +647,23 @@ def test_captured_call_with_forked_guided_filter(env):
     ws = rf.ops.gf_workspace(2, h, w, 3, 45, s.device, torch)
     with rf._ffi.debug_options(gf_one_stream=1):
         want = rf.ops.guided_filter_u8(g, s, 45, 3.0, iterations=2)
-    cap = rf.ops.CapturedCall(lambda: rf.ops.guided_filter_u8(g, s, 45, 3.0, iterations=2,
-                                                               out=out, workspace=ws))
+    # (the library forks from eight images on by itself; the switch makes two images fork)
+    with rf._ffi.debug_options(gf_force_two_streams=1):
+        cap = rf.ops.CapturedCall(lambda: rf.ops.guided_filter_u8(g, s, 45, 3.0, iterations=2,
+                                                                   out=out, workspace=ws))
     got = cap.replay()
     torch.cuda.synchronize()
     assert torch.equal(got, want)
+    # and a batch large enough to fork without the switch
+    g8, s8 = g.repeat(4, 1, 1, 1), s.repeat(4, 1, 1, 1)
+    out8 = torch.empty_like(s8)
+    ws8 = rf.ops.gf_workspace(8, h, w, 3, 45, s.device, torch)
+    cap8 = rf.ops.CapturedCall(lambda: rf.ops.guided_filter_u8(g8, s8, 45, 3.0, iterations=2,
+                                                                out=out8, workspace=ws8))
+    out8.zero_()
+    got8 = cap8.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(got8, want.repeat(4, 1, 1, 1))
 
 
 def test_captured_call_with_cnn_and_raw_entry_point_rules(env):
@@ -753,6 +765,8 @@ def test_gf_capture_on_one_thread_eager_on_another(env):
             errors.append(repr(exc))
 
     th = threading.Thread(target=eager)
+    opts = rf._ffi.debug_options(gf_force_two_streams=1)   # two images fork the side stream
+    opts.__enter__()
     th.start()
     try:
         side = torch.cuda.Stream()
@@ -766,6 +780,7 @@ def test_gf_capture_on_one_thread_eager_on_another(env):
     finally:
         stop.set()
         th.join()
+        opts.__exit__(None, None, None)
     assert not errors, errors
     assert eager_runs[0] >= 3
     for graph in graphs:
@@ -782,8 +797,8 @@ def test_two_streams_do_not_share_scratch(env):
     from tests import synth
     rf, co, torch = env
     h, w = 700, 900
-    # two images per call: each call forks the library's side stream for its second image, so
-    # the two callers also share that stream
+    # two images per call: with the switch each call forks a side stream of the library for its
+    # second image (one side stream per caller stream)
     ga = torch.from_numpy(np.stack([synth.flat_guide_u8(h, w, seed=1, cells=30),
                                     synth.flat_guide_u8(h, w, seed=11, cells=20)])).cuda()
     gb = torch.from_numpy(np.stack([synth.scene_u8(h, w, seed=2), synth.scene_u8(h, w, seed=12)])).cuda()
@@ -799,16 +814,17 @@ def test_two_streams_do_not_share_scratch(env):
     assert not torch.equal(want_r1, want_r2)
     torch.cuda.synchronize()
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
-    for _ in range(4):
-        with torch.cuda.stream(s1):
-            a = rf.ops.guided_filter_u8(ga, sa, 45, 3.0, iterations=2)
-            r1, _ = rf.ops.cnn_reflectance_u8(gb, weights=wts)
-        with torch.cuda.stream(s2):
-            b = rf.ops.guided_filter_u8(gb, sb, 45, 3.0, iterations=2)
-            r2, _ = rf.ops.cnn_reflectance_u8(gb, weights=wts2)
-        torch.cuda.synchronize()
-        assert torch.equal(a, want_a) and torch.equal(b, want_b)
-        assert torch.equal(r1, want_r1) and torch.equal(r2, want_r2)
+    for rnd in range(4):
+        with rf._ffi.debug_options(gf_force_two_streams=rnd % 2):   # with and without the inner fork
+            with torch.cuda.stream(s1):
+                a = rf.ops.guided_filter_u8(ga, sa, 45, 3.0, iterations=2)
+                r1, _ = rf.ops.cnn_reflectance_u8(gb, weights=wts)
+            with torch.cuda.stream(s2):
+                b = rf.ops.guided_filter_u8(gb, sb, 45, 3.0, iterations=2)
+                r2, _ = rf.ops.cnn_reflectance_u8(gb, weights=wts2)
+            torch.cuda.synchronize()
+            assert torch.equal(a, want_a) and torch.equal(b, want_b)
+            assert torch.equal(r1, want_r1) and torch.equal(r2, want_r2)
 
 
 @pytest.mark.parametrize("radius", [1, 2, 5, 7, 8, 13, 16, 17, 20, 30, 33, 47, 60, 64, 65, 77, 96, 97])
@@ -869,8 +885,11 @@ def test_gf_fused_stage2_in_place_chain_and_oracle(env, radius, eps):
     for seg_rows in (1, 17, 64, 1000):
         with rf._ffi.debug_options(gf_seg_rows=seg_rows):
             assert torch.equal(rf.ops.guided_filter_u8(g, s, radius, eps, iterations=3), got)
-    # everything on the caller's stream (the default forks a side stream for the second image)
+    # everything on the caller's stream / the second image on a side stream (the default forks
+    # from eight images on)
     with rf._ffi.debug_options(gf_one_stream=1):
+        assert torch.equal(rf.ops.guided_filter_u8(g, s, radius, eps, iterations=3), got)
+    with rf._ffi.debug_options(gf_force_two_streams=1):
         assert torch.equal(rf.ops.guided_filter_u8(g, s, radius, eps, iterations=3), got)
     one = rf._ffi.load_library().rf_gf_workspace_bytes(1, h, w, 3, 3, radius)
     ws = torch.empty(one, dtype=torch.uint8, device="cuda")
