@@ -21,6 +21,10 @@
  *                        the library, forked / joined with events inside the call); identical bytes
  *   "gf_force_two_streams"  guided filter: fork the side stream for every chunk of two or more
  *                        images (the default decides by batch size and src kind); identical bytes
+ *   "gf_guide_cache"     guided filter, experiment: an iterated call keeps the guide's window
+ *                        statistics of its first pass in the workspace (36 B per pixel) and later
+ *                        passes box-sum only the src quantities; identical bytes, measured slower
+ *                        (profiles/r03_gf_guide_cache.md), off by default
  *   "jbf_stage_only"     joint bilateral: stage the tile and return WITHOUT WRITING dst
  *                        (tools/jbf_tune.py --stage-only, timing only)
  */

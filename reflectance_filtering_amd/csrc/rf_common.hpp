@@ -83,6 +83,7 @@ enum DebugOption {
     kDbgGfSegRows,         // guided filter: rows per stage-1 segment (0 = chosen by the library)
     kDbgGfOneStream,       // guided filter: the whole chunk on the caller's stream (no side stream)
     kDbgGfForceTwoStreams, // guided filter: fork the side stream for any chunk of two or more images
+    kDbgGfGuideCache,      // guided filter: keep the guide statistics of the first pass of an iterated call (experiment)
     kDbgCount
 };
 int debug_get(int id);

@@ -49,29 +49,34 @@ namespace {
 constexpr int stage1_threads(int) { return 256; }
 constexpr int stage1_cols(int scn) { return scn == 1 ? 3 : 2; }
 
-template <int SCN>
+// Stage-1 quantities.  GUIDE = true: all of them, q: 0..2 I_g | 3..8 I_aI_b (00 01 02 11 12 22) |
+// 9.. p_s | then p_s*I_g (s major).  GUIDE = false (later passes of an iterated call, whose guide
+// statistics come from the record the first pass left): only p_s | p_s*I_g.
+template <int SCN, bool GUIDE = true>
 struct Quant {
-    static constexpr int NQ = 9 + 4 * SCN;
-    // q: 0..2 I_g | 3..8 I_aI_b (00 01 02 11 12 22) | 9.. p_s | then p_s*I_g (s major)
+    static constexpr int G0 = GUIDE ? 9 : 0;  // first src quantity
+    static constexpr int NQ = G0 + 4 * SCN;
     __device__ static inline void eval(const uint8_t *g, const uint8_t *p, uint32_t *v)
     {
         const uint32_t g0 = g[0], g1 = g[1], g2 = g[2];
-        v[0] = g0;
-        v[1] = g1;
-        v[2] = g2;
-        v[3] = g0 * g0;
-        v[4] = g0 * g1;
-        v[5] = g0 * g2;
-        v[6] = g1 * g1;
-        v[7] = g1 * g2;
-        v[8] = g2 * g2;
+        if (GUIDE) {
+            v[0] = g0;
+            v[1] = g1;
+            v[2] = g2;
+            v[3] = g0 * g0;
+            v[4] = g0 * g1;
+            v[5] = g0 * g2;
+            v[6] = g1 * g1;
+            v[7] = g1 * g2;
+            v[8] = g2 * g2;
+        }
 #pragma unroll
         for (int s = 0; s < SCN; s++) {
             const uint32_t ps = p[s];
-            v[9 + s] = ps;
-            v[9 + SCN + 3 * s + 0] = ps * g0;
-            v[9 + SCN + 3 * s + 1] = ps * g1;
-            v[9 + SCN + 3 * s + 2] = ps * g2;
+            v[G0 + s] = ps;
+            v[G0 + SCN + 3 * s + 0] = ps * g0;
+            v[G0 + SCN + 3 * s + 1] = ps * g1;
+            v[G0 + SCN + 3 * s + 2] = ps * g2;
         }
     }
 };
@@ -98,12 +103,17 @@ __device__ constexpr int sym(int i, int j)
     return i <= j ? (i * 3 - i * (i - 1) / 2 + (j - i)) : (j * 3 - j * (j - 1) / 2 + (i - j));
 }
 
-// Per-pixel algebra of guided_filter.cpp from the 9 + 4*SCN window means m (order of Quant):
-// covariance of the guide (+eps on the diagonal), its inverse by cofactors, and for every src
-// channel s the coefficients alpha_{s,g} (out[4s + g]) and beta_s (out[4s + 3]).  Every
-// operation is the separately rounded float op of the corresponding OpenCV helper.
-template <int SCN>
-__device__ inline void gf_pixel_algebra(const float *m, float eps_f, int eps_small, float *out)
+// Per-pixel algebra of guided_filter.cpp, every operation the separately rounded float op of the
+// corresponding OpenCV helper, in two halves:
+//   gf_guide_algebra  from the 9 guide means m (order of Quant): covariance of the guide (+eps on
+//                     the diagonal) and its inverse by cofactors -> gs[0..2] = mean I_g,
+//                     gs[3..8] = inverse (symmetric store).  Depends on the guide only: the passes
+//                     of an iterated call share it (kGsFloats floats per pixel).
+//   gf_src_algebra    from gs and the 4*SCN src means ms (p_s | p_s*I_g): for every src channel s
+//                     the coefficients alpha_{s,g} (out[4s + g]) and beta_s (out[4s + 3]).
+constexpr int kGsFloats = kGsFloatsPublic;
+
+__device__ inline void gf_guide_algebra(const float *m, float eps_f, int eps_small, float *gs)
 {
     const float *mI = m;
     float cov[6];
@@ -130,16 +140,25 @@ __device__ inline void gf_pixel_algebra(const float *m, float eps_f, int eps_sma
     det = __fadd_rn(det, __fmul_rn(cov[sym(2, 0)], inv[sym(2, 0)]));
     if (eps_small && fabsf(det) < 1e-6f)
         det = 1.f;
+    gs[0] = mI[0];
+    gs[1] = mI[1];
+    gs[2] = mI[2];
 #pragma unroll
     for (int e = 0; e < 6; e++)
-        inv[e] = __fdiv_rn(inv[e], det);
+        gs[3 + e] = __fdiv_rn(inv[e], det);
+}
+
+template <int SCN>
+__device__ inline void gf_src_algebra(const float *gs, const float *ms, float *out)
+{
+    const float *mI = gs, *inv = gs + 3;
 #pragma unroll
     for (int s = 0; s < SCN; s++) {
-        const float mp = m[9 + s];
+        const float mp = ms[s];
         float cp[3];
 #pragma unroll
         for (int g = 0; g < 3; g++)
-            cp[g] = __fsub_rn(m[9 + SCN + 3 * s + g], __fmul_rn(mp, mI[g]));
+            cp[g] = __fsub_rn(ms[SCN + 3 * s + g], __fmul_rn(mp, mI[g]));
         float beta = mp;
 #pragma unroll
         for (int g = 0; g < 3; g++) {
@@ -151,6 +170,15 @@ __device__ inline void gf_pixel_algebra(const float *m, float eps_f, int eps_sma
         }
         out[4 * s + 3] = beta;
     }
+}
+
+// both halves: from the 9 + 4*SCN window means m (order of Quant<SCN, true>)
+template <int SCN>
+__device__ inline void gf_pixel_algebra(const float *m, float eps_f, int eps_small, float *out)
+{
+    float gs[kGsFloats];
+    gf_guide_algebra(m, eps_f, eps_small, gs);
+    gf_src_algebra<SCN>(gs, m + 9, out);
 }
 
 // colour[img] != 0  <=>  some pixel of the 3-channel image has unequal channels.
@@ -185,15 +213,24 @@ __global__ __launch_bounds__(256) void gf_grey_probe_kernel(const uint8_t *__res
 // grid: (strips, row segments, images).  ab: [img][SPX][h][w][4] float (g<3 alpha, g=3 beta).
 // SCN = src channels computed, SPX = src bytes per pixel (SCN, or 3 with SCN = 1 for a grey
 // 3-channel image whose first channel stands for all three).
-template <int SCN, int SPX>
+// MODE (iterated calls: the guide is the same in every pass, /root/reference/README.md:66; only
+// kS1Full is used unless the experiment switch "gf_guide_cache" is set, see rf_gf_u8):
+//   kS1Full    all 9 + 4*SCN quantities, nothing kept
+//   kS1Keep    the same, and the guide half of the algebra (mean I_g, inverse covariance: kGsFloats
+//              floats per pixel) is stored to gs                         - first pass
+//   kS1Reuse   only the 4*SCN src quantities are box-summed; the guide half is read from gs
+//              (requested at the top of a row, used at its end)          - later passes
+enum { kS1Full = 0, kS1Keep = 1, kS1Reuse = 2 };
+template <int SCN, int SPX, int MODE>
 __global__ __launch_bounds__(stage1_threads(SCN)) void gf_stage1_kernel(
     const uint8_t *__restrict__ guide, const uint8_t *__restrict__ src, float *__restrict__ ab,
     int h, int w, int radius, float eps_f, int eps_small, int seg_rows,
-    const int *__restrict__ colour)
+    const int *__restrict__ colour, float *__restrict__ gs)
 {
     if (wrong_variant<SCN>(colour, blockIdx.z))
         return;
-    constexpr int NQ = Quant<SCN>::NQ;
+    using Q = Quant<SCN, MODE != kS1Reuse>;
+    constexpr int NQ = Q::NQ;
     constexpr int kAThreads = stage1_threads(SCN), kAWaves = kAThreads / 64;
     constexpr int kACols = stage1_cols(SCN);
     constexpr int kACW = kAThreads * kACols;
@@ -210,6 +247,7 @@ __global__ __launch_bounds__(stage1_threads(SCN)) void gf_stage1_kernel(
     const uint8_t *gimg = guide + (size_t)blockIdx.z * npx * 3;
     const uint8_t *simg = src + (size_t)blockIdx.z * npx * SPX;
     float *abimg = ab + (size_t)blockIdx.z * npx * (SPX * 4);
+    float *gsimg = MODE == kS1Full ? nullptr : gs + (size_t)blockIdx.z * npx * kGsFloats;
     const int ks = 2 * radius + 1;
     const double scale = 1.0 / (double)(ks * ks);
 
@@ -234,7 +272,7 @@ __global__ __launch_bounds__(stage1_threads(SCN)) void gf_stage1_kernel(
         for (int k = 0; k < kACols; k++) {
             uint32_t v[NQ];
             const size_t pix = (size_t)gy * w + gx[k];
-            Quant<SCN>::eval(gimg + pix * 3, simg + pix * SPX, v);
+            Q::eval(gimg + pix * 3, simg + pix * SPX, v);
 #pragma unroll
             for (int q = 0; q < NQ; q++)
                 V[k][q] = add ? V[k][q] + v[q] : V[k][q] - v[q];
@@ -263,7 +301,41 @@ __global__ __launch_bounds__(stage1_threads(SCN)) void gf_stage1_kernel(
             wave_acc[q][tid] = 0;
     __syncthreads();
 
+    bool col_ok[kACols], all_ok = true;
+#pragma unroll
+    for (int k = 0; k < kACols; k++) {
+        const int c = tid * kACols + k;
+        col_ok[k] = !(c < radius || c >= kACW - radius || xs - radius + c >= w);
+        all_ok = all_ok && col_ok[k];
+    }
     for (int y = ys; y < ye; y++) {
+        // later passes: the guide records of the row's pixels, used after the barriers
+        // (gs: [img][row][kGsFloats][w] - the floats of a record are w apart, so the lanes of a wave
+        //  read and write runs of consecutive floats; interleaved 36-byte records made every load
+        //  and store instruction of a wave touch 54 cache lines and cost more than they saved)
+        float gsr[kACols][kGsFloats];
+        if (MODE == kS1Reuse) {
+            const float *rec = gsimg + (size_t)y * kGsFloats * w + (xs - radius + tid * kACols);
+            if (all_ok) {
+#pragma unroll
+                for (int e = 0; e < kGsFloats; e++) {
+                    float t[kACols];
+                    __builtin_memcpy(t, rec + (size_t)e * w, sizeof(t));
+#pragma unroll
+                    for (int k = 0; k < kACols; k++)
+                        gsr[k][e] = t[k];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < kACols; k++) {
+                    if (!col_ok[k])
+                        continue;
+#pragma unroll
+                    for (int e = 0; e < kGsFloats; e++)
+                        gsr[k][e] = rec[(size_t)e * w + k];
+                }
+            }
+        }
         add_row(y + radius, true);
         // inclusive prefix over the strip's columns, per quantity.  The six DPP steps of the wave
         // scan run stage by stage across the quantities: back to back on one quantity every step
@@ -331,7 +403,19 @@ __global__ __launch_bounds__(stage1_threads(SCN)) void gf_stage1_kernel(
                 m[q] = mean_of(pfx[q][c + radius + 1] - pfx[q][c - radius], scale);
             const size_t pix = (size_t)y * w + x;
             float ab_px[4 * SCN];
-            gf_pixel_algebra<SCN>(m, eps_f, eps_small, ab_px);
+            if (MODE == kS1Reuse) {
+                gf_src_algebra<SCN>(gsr[k], m, ab_px);
+            } else {
+                float gsn[kGsFloats];
+                gf_guide_algebra(m, eps_f, eps_small, gsn);
+                gf_src_algebra<SCN>(gsn, m + 9, ab_px);
+                if (MODE == kS1Keep) {
+                    float *rec = gsimg + (size_t)y * kGsFloats * w + x;
+#pragma unroll
+                    for (int e = 0; e < kGsFloats; e++)
+                        rec[(size_t)e * w] = gsn[e];
+                }
+            }
             // the four planes of a src channel (alpha_0..2, beta) interleaved per pixel: one
             // 16-byte store, and stage 2 reads 256-byte runs per image row instead of 64-byte ones
 #pragma unroll
@@ -735,7 +819,7 @@ extern "C" size_t rf_gf_workspace_bytes(int n, int h, int w, int guide_cn, int s
     const size_t per_img = (size_t)h * w * (4 * src_cn) * (sizeof(float) + sizeof(double));
     // enough images in flight to fill the chip and to make the tails of the launches small: capped
     // at 1/16 of the device's memory, at most 16 GiB (6 GiB when no device can be asked).  C5 shard
-    // (128 x 4K, 3 passes): 91.5 ms with 6 GiB (13 images per chunk), 86.6 ms with 16 GiB (36).
+    // (128 x 4K, 3 passes, round 2): 91.5 ms with 6 GiB (13 images per chunk), 86.6 ms with 16 GiB (36).
     size_t imgs = (size_t)n;
     const size_t cap = rf::gf_workspace_cap();
     if (imgs * per_img > cap)
@@ -789,7 +873,18 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
                        npx < ((size_t)1 << 28);
     const int nb = ceil_div(w, kSB);
     const size_t per_img_fused = (size_t)np * (npx * sizeof(float) + (size_t)nb * h * sizeof(double));
-    const size_t per_img_used = fused ? per_img_fused : per_img;
+    // EXPERIMENT, off by default (debug option "gf_guide_cache"): iterated calls keep the guide half
+    // of the per-pixel algebra (kGsFloats floats per pixel) from the first pass for the later ones,
+    // which then box-sum only the 4 src quantities - 3x fewer VALU instructions in stage 1, but 36
+    // more bytes per pixel and pass through a memory system the other kernels of the pass already
+    // load.  Measured twice (interleaved 36-byte records; row-planar records with coalesced
+    // accesses), 8 x 4K grey, kernels alone: stage 1 of a later pass 1.085 ms against 1.044 ms
+    // without the record, the pass that writes it 1.69 ms; C5 shard 11.4 against 14.0 GP/s
+    // (profiles/r03_gf_guide_cache.md).  Kept as a switch so that the measurement can be repeated.
+    const size_t gs_bytes = npx * kGsFloats * sizeof(float);
+    const bool keep_gs = iterations > 1 && debug_get(kDbgGfGuideCache) &&
+                         workspace_bytes - header >= (fused ? per_img_fused : per_img) + gs_bytes;
+    const size_t per_img_used = (fused ? per_img_fused : per_img) + (keep_gs ? gs_bytes : 0);
     int chunk = (int)std::min<size_t>((size_t)n, (workspace_bytes - header) / per_img_used);
     if (chunk > 16383)
         chunk = 16383;
@@ -820,6 +915,7 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
         double *rows = reinterpret_cast<double *>(ws);
         float *ab = reinterpret_cast<float *>(rows + (fused ? (size_t)m * np * nb * h
                                                             : (size_t)m * np * npx));
+        float *gs = keep_gs ? ab + (size_t)m * np * npx : nullptr;  // [m][h][kGsFloats][w]
         const uint8_t *g0 = guide + (size_t)i0 * npx * 3;
         uint8_t *d0 = dst + (size_t)i0 * npx * src_cn;
         // row segments: enough workgroups to fill 256 CUs, but segments no shorter than 2r+1.
@@ -837,15 +933,25 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
         for (int it = 0; it < iterations; it++) {
             const uint8_t *s0 = (it == 0 ? src : (const uint8_t *)dst) + (size_t)i0 * npx * src_cn;
             const dim3 ga3(strips3, segs, m), ga1(strips1, segs, m);
-            if (src_cn == 3) {
-                hipLaunchKernelGGL((gf_stage1_kernel<3, 3>), ga3, dim3(stage1_threads(3)), 0, st, g0, s0,
-                                   ab, h, w, radius, eps_f, eps_small, seg_rows, colour);
-                hipLaunchKernelGGL((gf_stage1_kernel<1, 3>), ga1, dim3(stage1_threads(1)), 0, st, g0, s0,
-                                   ab, h, w, radius, eps_f, eps_small, seg_rows, colour);
-            } else {
-                hipLaunchKernelGGL((gf_stage1_kernel<1, 1>), ga1, dim3(stage1_threads(1)), 0, st, g0, s0,
-                                   ab, h, w, radius, eps_f, eps_small, seg_rows, colour);
-            }
+#define RF_GF_STAGE1(MODE)                                                                         \
+    do {                                                                                           \
+        if (src_cn == 3) {                                                                         \
+            hipLaunchKernelGGL((gf_stage1_kernel<3, 3, MODE>), ga3, dim3(stage1_threads(3)), 0, st, \
+                               g0, s0, ab, h, w, radius, eps_f, eps_small, seg_rows, colour, gs);  \
+            hipLaunchKernelGGL((gf_stage1_kernel<1, 3, MODE>), ga1, dim3(stage1_threads(1)), 0, st, \
+                               g0, s0, ab, h, w, radius, eps_f, eps_small, seg_rows, colour, gs);  \
+        } else {                                                                                   \
+            hipLaunchKernelGGL((gf_stage1_kernel<1, 1, MODE>), ga1, dim3(stage1_threads(1)), 0, st, \
+                               g0, s0, ab, h, w, radius, eps_f, eps_small, seg_rows, colour, gs);  \
+        }                                                                                          \
+    } while (0)
+            if (!keep_gs)
+                RF_GF_STAGE1(kS1Full);
+            else if (it == 0)
+                RF_GF_STAGE1(kS1Keep);
+            else
+                RF_GF_STAGE1(kS1Reuse);
+#undef RF_GF_STAGE1
             const int row_blocks = ceil_div(h, kBRows);
             if (fused) {
                 const GfFusedArgs fa = {ab, rows, g0, d0, m, h, w, nb, src_cn, colour, st};

@@ -29,6 +29,7 @@ namespace rf {
 constexpr int kGfFusedMaxRadius = 96;
 constexpr int kSB = 16;     // columns per state block and per column-walk workgroup
 constexpr int kBRows = 64;  // rows per row-walk workgroup (one lane per row)
+constexpr int kGsFloatsPublic = 9;  // floats per pixel of the guide record kept by iterated calls
 
 // Does this workgroup's instantiation apply to image img?  (colour == nullptr: no choice to make)
 template <int SCN>

@@ -827,6 +827,36 @@ def test_two_streams_do_not_share_scratch(env):
             assert torch.equal(r1, want_r1) and torch.equal(r2, want_r2)
 
 
+def test_gf_guide_cache_switch(env):
+    """Experiment switch gf_guide_cache (the first pass of an iterated call leaves the guide half of
+    the per-pixel algebra in the workspace, later passes box-sum only the src quantities): the
+    bytes of the default path, for grey / colour / mixed batches, fused and two-kernel stage 2, and
+    with a workspace too small for the record (falls back to recomputing)."""
+    from tests import synth
+    rf, co, torch = env
+    h, w = 150, 333
+    guide = synth.flat_guide_u8(h, w, seed=5, cells=20)
+    srcs = [synth.scene_u8(h, w, seed=6), synth.reflectance_like_u8(h, w, seed=7)]
+    g = torch.from_numpy(np.stack([guide, guide])).cuda()
+    s = torch.from_numpy(np.stack(srcs)).cuda()
+    one = torch.from_numpy(srcs[1][None, :, :, :1].copy()).cuda()
+    for radius in (9, 45, 97):
+        want = rf.ops.guided_filter_u8(g, s, radius, 3.0, iterations=3)
+        want1 = rf.ops.guided_filter_u8(g[:1], one, radius, 3.0, iterations=2)
+        with rf._ffi.debug_options(gf_guide_cache=1):
+            assert torch.equal(rf.ops.guided_filter_u8(g, s, radius, 3.0, iterations=3), want)
+            assert torch.equal(rf.ops.guided_filter_u8(g[:1], one, radius, 3.0, iterations=2), want1)
+            small = rf._ffi.load_library().rf_gf_workspace_bytes(1, h, w, 3, 3, radius)
+            ws = torch.empty(small, dtype=torch.uint8, device="cuda")   # one image, 3 channels: room
+            assert torch.equal(rf.ops.guided_filter_u8(g, s, radius, 3.0, iterations=3, workspace=ws), want)
+    cur = srcs[0]
+    for _ in range(3):
+        cur = co.guided_filter(guide, cur, 45, 3.0)
+    with rf._ffi.debug_options(gf_guide_cache=1):
+        got = rf.ops.guided_filter_u8(g[:1], s[:1], 45, 3.0, iterations=3)
+    assert np.array_equal(got[0].cpu().numpy(), cur)
+
+
 @pytest.mark.parametrize("radius", [1, 2, 5, 7, 8, 13, 16, 17, 20, 30, 33, 47, 60, 64, 65, 77, 96, 97])
 def test_gf_fused_stage2_any_radius(env, radius):
     """The fused stage 2 is instantiated for every radius 1..96 (97: the row-sum / column-sum pair):
