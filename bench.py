@@ -63,6 +63,10 @@ def parse_args(argv=None):
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--sigma-color", type=float, default=20.0)
     ap.add_argument("--sigma-spatial", type=float, default=22.0)
+    ap.add_argument("--src", choices=("grey", "colour"), default="grey",
+                    help="joint-bilateral workloads: the src image - the grey CNN-style map the "
+                         "reference filters (default, the metric's input) or a 3-channel colour "
+                         "image (profiling the colour tap loop; named in config.workload)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="target CPU time of the cpu_baseline sample (0 disables it)")
     ap.add_argument("--no-extras", "--no-colour-src", dest="no_extras", action="store_true",
@@ -328,13 +332,18 @@ class Workload:
         scene, grey = synth_batch(torch, n, h, w, seed, device)
         if kind == "jbf":
             self.joint, self.src = scene, grey
+            if getattr(args, "src", "grey") == "colour":
+                self.src = scene.roll(shifts=(37, 91), dims=(1, 2)).contiguous()
             self.dst = torch.empty_like(grey)
             self.step = lambda: rf.ops.joint_bilateral_u8(self.joint, self.src, -1, sc, ss,
                                                           out=self.dst)
             self.bytes_per_px = JBF_BYTES_PER_PX
             radius = int(round(ss * 1.5))
             self.name = ("joint bilateral c=%g s=%g (radius %d), batch %d x %dx%d uint8 BGR per "
-                         "GPU, RGB scene as joint, grey map as src" % (sc, ss, radius, n, w, h))
+                         "GPU, RGB scene as joint, %s as src"
+                         % (sc, ss, radius, n, w, h,
+                            "3-channel colour image" if getattr(args, "src", "grey") == "colour"
+                            else "grey map"))
         elif kind == "gf3":
             self.guide, self.src = flat_guide(scene), grey
             del scene

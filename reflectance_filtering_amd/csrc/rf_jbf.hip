@@ -1885,6 +1885,7 @@ extern "C" int rf_jbf_u8(const uint8_t *joint, const uint8_t *src, uint8_t *dst,
             return rc;                                                                            \
         done = true;                                                                              \
     }
+            RF_T64(32, 32, 144)
             RF_T64(32, 16, 144)
             RF_T64(16, 8, 144)
             RF_T64(8, 4, 144)

@@ -87,13 +87,25 @@ def main():
                        "MI355X_MICROARCH.md HBM section)" % f16}
     with open(os.path.join(OUT, "jbf_pmc_traffic.json"), "w") as fh:
         json.dump(traffic, fh, indent=1)
-    # ---- SQ counters
-    sq, sqn = counters(newest("prof_sq/*/*counter_collection.csv"), "jbf")
-    gr, _ = counters(newest("prof_grbm/*/*counter_collection.csv"), "jbf")
-    first = min(sq)
-    c = sq[first]
-    gui = gr[min(gr)]["GRBM_GUI_ACTIVE"] / 8.0
+    # ---- SQ counters: grey-src launch (the metric's input) and, when profiled, colour-src launch
+    def sq_column(sq_dir, grbm_dir):
+        sq_path = newest("%s/*/*counter_collection.csv" % sq_dir)
+        gr_path = newest("%s/*/*counter_collection.csv" % grbm_dir)
+        if not sq_path or not gr_path:
+            return None
+        sq, sqn = counters(sq_path, "jbf")
+        gr, _ = counters(gr_path, "jbf")
+        first = max(sq, key=lambda d: sq[d]["SQ_INSTS_VALU"])      # the big launch, not a warm-up probe
+        c = sq[first]
+        gui = max(v["GRBM_GUI_ACTIVE"] for v in gr.values()) / 8.0
+        # kernel duration of that dispatch from the trace of the GRBM pass
+        return {"name": sqn[first], "c": c, "gui": gui}
+
     simds, cus = 1024.0, 256.0
+    cols = [("grey src (the metric's launch shape, 32 images)", sq_column("prof_sq", "prof_grbm"))]
+    colour = sq_column("prof_sq_colour", "prof_grbm_colour")
+    if colour:
+        cols.append(("3-channel colour src (32 images)", colour))
     lines += [
         "# %s — rocprofv3 summaries for bench.py (one MI355X)" % TAG, "",
         "Kernel: `%s`, launch = %d x %dx%d images." % (short_name(jbf["Name"]), n, w_, h), "",
@@ -101,6 +113,7 @@ def main():
         "| bench.py value | %.0f MP/s (%.1f ms per 256-image step) |" % (bench["value"], bench["ms_per_step"]),
         "| kernel average duration, `--kernel-trace --stats` (%s calls) | %.2f ms |" % (jbf["Calls"], avg_ms),
         "| kernel duration from HIP events inside bench.py | %.2f ms |" % bench["roofline"]["kernel_ms"],
+        "| shader clock under the launch (bench.py probe, s_memtime / s_memrealtime) | %.0f MHz |" % bench.get("valu", {}).get("clock_mhz", float("nan")),
         "| algorithmic bytes per launch (9 B/px) | %.3f GB |" % (traffic["algorithmic_bytes_per_launch"] / 1e9),
         "| achieved on algorithmic bytes | %.1f GB/s = %.3f %% of 8 TB/s |" % (bench["roofline"]["achieved"], 100 * bench["roofline"]["frac"]),
         "| WRITE_SIZE per launch | %.3f GB (algorithmic 3 B/px = %.3f GB) |" % (write / 1e9, 3.0 * n * h * w_ / 1e9),
@@ -111,19 +124,32 @@ def main():
         "| colour-src launch (secondary) | %.0f MP/s |" % bench.get("colour_src", {}).get("value", float("nan")),
         "| CPU baseline (oracle, %d threads) | %.2f MP/s |" % (bench["cpu_baseline"]["cores"], bench["cpu_baseline"]["value"]),
         "",
-        "SQ counters, 32-image launch of the same kernel (`%s`):" % sqn[first], "",
-        "| counter | value | reading |", "|---|---|---|",
+        "SQ counters of the same kernel (`%s`), one column per src kind: the grey tap loop issues 26 "
+        "VALU instructions per 4-output column step, the colour loop 44 (three accumulators per "
+        "output)." % cols[0][1]["name"], "",
+        "| counter | " + " | ".join(t for t, _ in cols) + " | reading |",
+        "|---|" + "---|" * len(cols) + "---|",
     ]
-    wave = c["SQ_WAVE_CYCLES"]
+
+    def row(label, fn, reading):
+        return "| %s | %s | %s |" % (label, " | ".join(fn(v["c"], v["gui"]) for _, v in cols), reading)
+
     lines += [
-        "| GRBM_GUI_ACTIVE / 8 | %.3e cycles | kernel length in shader cycles |" % gui,
-        "| SQ_INSTS_VALU | %.3e | %.2f cycles per VALU wave-instruction per SIMD |" % (c["SQ_INSTS_VALU"], gui * simds / c["SQ_INSTS_VALU"]),
-        "| SQ_INSTS_LDS | %.3e | %.2f VALU per LDS instruction |" % (c["SQ_INSTS_LDS"], c["SQ_INSTS_VALU"] / c["SQ_INSTS_LDS"]),
-        "| SQ_LDS_IDX_ACTIVE | %.3e | LDS busy %.0f %% of the kernel |" % (c["SQ_LDS_IDX_ACTIVE"], 100 * c["SQ_LDS_IDX_ACTIVE"] / cus / gui),
-        "| SQ_LDS_BANK_CONFLICT | %.3e | %.2f %% of LDS-active cycles |" % (c["SQ_LDS_BANK_CONFLICT"], 100 * c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]),
-        "| SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES | %.0f %% | share of wave time issuing |" % (100 * c["SQ_ACTIVE_INST_ANY"] / wave),
-        "| SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES | %.0f %% | ready but not issued (pipe busy) |" % (100 * c["SQ_WAIT_INST_ANY"] / wave),
-        "| SQ_WAIT_ANY / SQ_WAVE_CYCLES | %.0f %% | parked in s_waitcnt / barrier |" % (100 * c["SQ_WAIT_ANY"] / wave),
+        row("GRBM_GUI_ACTIVE / 8", lambda c, g: "%.3e" % g, "kernel length in shader cycles"),
+        row("SQ_INSTS_VALU", lambda c, g: "%.3e" % c["SQ_INSTS_VALU"], "VALU wave-instructions"),
+        row("cycles per VALU wave-instruction per SIMD", lambda c, g: "%.2f" % (g * simds / c["SQ_INSTS_VALU"]),
+            "floor 2.0 (one per 2 cycles per SIMD)"),
+        row("VALU per LDS instruction", lambda c, g: "%.2f" % (c["SQ_INSTS_VALU"] / c["SQ_INSTS_LDS"]), ""),
+        row("LDS busy (SQ_LDS_IDX_ACTIVE)", lambda c, g: "%.0f %%" % (100 * c["SQ_LDS_IDX_ACTIVE"] / cus / g),
+            "share of the kernel"),
+        row("bank conflicts", lambda c, g: "%.2f %%" % (100 * c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]),
+            "of LDS-active cycles"),
+        row("issuing (SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES)", lambda c, g: "%.0f %%" % (100 * c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"]),
+            "share of wave time"),
+        row("ready, not issued (SQ_WAIT_INST_ANY)", lambda c, g: "%.0f %%" % (100 * c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"]),
+            "pipe busy"),
+        row("parked (SQ_WAIT_ANY)", lambda c, g: "%.0f %%" % (100 * c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]),
+            "s_waitcnt / barrier"),
     ]
     with open(os.path.join(OUT, "%s_jbf_pmc.md" % TAG), "w") as fh:
         fh.write("\n".join(lines) + "\n")
