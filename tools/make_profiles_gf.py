@@ -77,7 +77,7 @@ def main():
             f, w = 2.0 * fe.get(k, 0.0), wr.get(k, 0.0)
             if s["avg_ms"] < 0.02:        # flag zeroing / probes / workgroups of the other variant
                 continue
-            per_pass = max(1, s["calls"] // 3)
+            per_pass = 1 if run == "cnn" else max(1, s["calls"] // 3)
             tot_ms += s["avg_ms"] * per_pass
             tot_b += (f + w) * per_pass
             rec[k] = {"avg_ms": s["avg_ms"], "launches_per_pass": per_pass, "fetch_bytes": f,
@@ -87,6 +87,12 @@ def main():
         wall_ms = tot_ms
         wall_note = "kernel durations added up"
         wj = one("gf_profile_wall_%s.json" % {"gf": "grey", "gfc": "colour"}.get(run, "none"))
+        ev = one("%s_cnn_events.json" % TAG) if run == "cnn" else None
+        if ev:
+            evd = json.load(open(ev))
+            wall_ms = evd["event_ms_median"]
+            wall_note = ("median of HIP events around the same %d launches, in the same process, "
+                         "under the profiler" % evd["launches"])
         if wj:
             wall_ms = json.load(open(wj))["wall_ms"]
             wall_note = ("wall time of a call, HIP events, under the profiler; the two halves of the "

@@ -28,5 +28,7 @@ for pmc in "" FETCH_SIZE WRITE_SIZE; do
     run gf "$pmc" python3 tools/gf_profile.py "$NB" 2160 3840 grey 1 $WALL
     run gfc "$pmc" python3 tools/gf_profile.py "$NB" 2160 3840 colour 1 $WALL
     run cnn "$pmc" python3 tools/cnn_profile.py 256
+    # event timing of the same launches as the --stats pass (counter passes serialise and slow the kernels)
+    [ -z "$pmc" ] && cp "$OUT/cnn_profile_events.json" "$OUT/${TAG}_cnn_events.json"
 done
 ls "$OUT"
