@@ -1,0 +1,95 @@
+"""GPU suite: seeded random cases against the ORACLE (not against another kernel), sized so that
+the C oracle answers in milliseconds - every radius of the fused guided filter (1..96) and beyond,
+every border type, channel combination and flag of the joint bilateral, chained passes, batches
+that mix grey and colour images.  Bounded by time: `RF_FUZZ_SECONDS` (default 40) per test.
+"""
+import os
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SECONDS = float(os.environ.get("RF_FUZZ_SECONDS", "40"))
+
+
+@pytest.fixture(scope="module")
+def env(built):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device visible")
+    import reflectance_filtering_amd as rf
+    from oracle import c_oracle as co
+    torch.cuda.set_device(0)
+    return rf, co, torch
+
+
+def _image(rng, h, w, c, kind):
+    """uint8 [h,w,c]: smooth field, posterised field, white noise or a constant."""
+    if kind == 0:
+        yy, xx = np.mgrid[0:h, 0:w]
+        base = sum(np.sin(xx * rng.uniform(0.02, 0.4) + yy * rng.uniform(0.02, 0.4) + rng.uniform(0, 6))
+                   for _ in range(3))
+        img = 128 + 40 * base[..., None] + rng.normal(0, 6, (h, w, c))
+    elif kind == 1:
+        img = rng.integers(0, 5, (h // 7 + 1, w // 9 + 1, c)).repeat(7, 0).repeat(9, 1)[:h, :w] * 60 + 7
+    elif kind == 2:
+        img = rng.integers(0, 256, (h, w, c))
+    else:
+        img = np.full((h, w, c), int(rng.integers(0, 256)))
+    return np.clip(np.round(img), 0, 255).astype(np.uint8)
+
+
+def test_guided_filter_random_cases_match_the_oracle(env):
+    rf, co, torch = env
+    rng = np.random.default_rng(2024)
+    t_end = time.time() + SECONDS
+    cases = 0
+    while time.time() < t_end or cases < 12:
+        h, w = int(rng.integers(1, 150)), int(rng.integers(1, 220))
+        radius = int(rng.integers(1, 101)) if rng.random() < 0.8 else int(rng.choice([45, 52, 120]))
+        eps = float(rng.choice([3.0, 7.0, 0.5, 1e-3, 200.0]))
+        iters = int(rng.choice([1, 1, 2, 3]))
+        n = int(rng.integers(1, 4))
+        scn = int(rng.choice([1, 3]))
+        guides = [_image(rng, h, w, 3, int(rng.integers(0, 4))) for _ in range(n)]
+        srcs = []
+        for _ in range(n):
+            s = _image(rng, h, w, scn, int(rng.integers(0, 3)))
+            if scn == 3 and rng.random() < 0.4:          # a grey image among colour ones
+                s = np.repeat(s[:, :, :1], 3, axis=2)
+            srcs.append(s)
+        got = rf.ops.guided_filter_u8(torch.from_numpy(np.stack(guides)).cuda(),
+                                      torch.from_numpy(np.stack(srcs)).cuda(), radius, eps,
+                                      iterations=iters).cpu().numpy()
+        for i in range(n):
+            cur = srcs[i]
+            for _ in range(iters):
+                cur = co.guided_filter(guides[i], cur, radius, eps).reshape(srcs[i].shape)
+            assert np.array_equal(got[i], cur), (cases, h, w, radius, eps, iters, scn, i)
+        cases += 1
+    print("guided-filter fuzz: %d cases" % cases)
+
+
+def test_joint_bilateral_random_cases_match_the_oracle(env):
+    rf, co, torch = env
+    rng = np.random.default_rng(4048)
+    t_end = time.time() + SECONDS
+    cases = 0
+    while time.time() < t_end or cases < 12:
+        h, w = int(rng.integers(1, 110)), int(rng.integers(1, 150))
+        jcn, scn = int(rng.choice([1, 3])), int(rng.choice([1, 3]))
+        joint = _image(rng, h, w, jcn, int(rng.integers(0, 4)))
+        src = _image(rng, h, w, scn, int(rng.integers(0, 3)))
+        ss = float(rng.choice([22.0, 28.0, 5.0, 12.3, 34.0, 1.0]))
+        sc = float(rng.choice([20.0, 15.0, 4.0, 60.0, 0.5]))
+        d = int(rng.choice([-1, -1, 5, 9, 31]))
+        border = int(rng.choice([0, 1, 2, 3, 4]))
+        got = rf.ops.joint_bilateral_u8(torch.from_numpy(joint[None]).cuda(),
+                                        torch.from_numpy(src[None]).cuda(), d, sc, ss,
+                                        border=border).cpu().numpy()[0]
+        want = co.joint_bilateral_filter(joint, src, d, sc, ss, border=border).reshape(src.shape)
+        assert np.array_equal(got, want), (cases, h, w, jcn, scn, sc, ss, d, border)
+        cases += 1
+    print("joint-bilateral fuzz: %d cases" % cases)
