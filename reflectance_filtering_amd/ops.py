@@ -9,6 +9,7 @@ from . import _ffi
 
 _gf_workspaces = {}
 _GF_CACHE_PER_DEVICE = 4
+_GF_CACHE_BYTES_PER_DEVICE = 32 << 30     # ... and at most this much scratch kept per device
 _cnn_consts = {}
 
 
@@ -52,8 +53,7 @@ def gf_workspace(n, h, w, scn, radius, device, torch):
     """Guided-filter scratch for the CURRENT stream of `device`, cached per (device, stream):
     two streams (or threads with their own streams) never share planes.  The cache keeps one
     buffer per key, sized by rf_gf_workspace_bytes (capped at 1/16 of the device's memory, at most
-    16 GiB); release_workspaces()
-    drops them."""
+    16 GiB), at most four buffers and 32 GiB per device; release_workspaces() drops them."""
     lib = _ffi.load_library()
     need = lib.rf_gf_workspace_bytes(n, h, w, 3, scn, radius)
     dev = device.index if device.index is not None else torch.cuda.current_device()
@@ -67,6 +67,10 @@ def gf_workspace(n, h, w, scn, radius, device, torch):
         mine = [k for k in _gf_workspaces if k[0] == dev]
         for k in mine[:max(0, len(mine) - (_GF_CACHE_PER_DEVICE - 1))]:
             del _gf_workspaces[k]
+        mine = [k for k in _gf_workspaces if k[0] == dev]       # least recently used first
+        held = sum(_gf_workspaces[k].numel() for k in mine)
+        while mine and held + need > _GF_CACHE_BYTES_PER_DEVICE:
+            held -= _gf_workspaces.pop(mine.pop(0)).numel()
         ws = torch.empty(need, dtype=torch.uint8, device=device)
     _gf_workspaces[key] = ws
     return ws

@@ -84,6 +84,104 @@ def test_no_packed_f32_op_sel_on_scalar_operands(built, tmp_path):
     assert not bad, bad[:5]
 
 
+def _disassembly(tmp_path_factory):
+    tool = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(tool):
+        pytest.skip("llvm-objdump not available")
+    import glob
+    import shutil
+    d = tmp_path_factory.mktemp("disasm")
+    copy = str(d / "librf_hip.so")
+    shutil.copy(_ffi.LIB_PATH, copy)
+    subprocess.check_output([tool, "--offloading", copy], stderr=subprocess.STDOUT)
+    funcs = {}
+    for obj in glob.glob(copy + ".*gfx950"):
+        name = None
+        for line in subprocess.check_output([tool, "-d", obj]).decode().splitlines():
+            m = re.match(r"^[0-9a-f]+ <([^>]+)>:", line)
+            if m:
+                name = m.group(1)
+                funcs[name] = []
+                continue
+            m = re.match(r"^\s+([a-z_0-9]+)\s*([^/]*)", line)
+            if m and name is not None:
+                funcs[name].append((m.group(1), m.group(2).strip()))
+    return funcs
+
+
+@pytest.fixture(scope="module")
+def disassembly(built, tmp_path_factory):
+    return _disassembly(tmp_path_factory)
+
+
+def _sgprs(text):
+    regs = set()
+    for a, b in re.findall(r"\bs\[(\d+):(\d+)\]", text):
+        regs.update(range(int(a), int(b) + 1))
+    regs.update(int(a) for a in re.findall(r"\bs(\d+)\b", text))
+    return regs
+
+
+def test_inline_asm_scalar_loads_are_not_touched_before_their_wait(disassembly):
+    """The CNN kernels issue s_load_dwordx16 / x2 in one inline-asm statement and wait for them in a
+    later one; the compiler does not know the loads are in flight, so nothing it places in between
+    may read or write their destination SGPRs (it could copy or spill stale values).  Checked on
+    the machine code of every kernel that streams weights this way."""
+    checked = 0
+    for name, insts in disassembly.items():
+        if "cnn_reflectance" not in name:
+            continue
+        pending = set()
+        for op, args in insts:
+            if op.startswith("s_load_dword"):
+                dst = args.split(",")[0]
+                rest = ",".join(args.split(",")[1:])
+                assert not (_sgprs(rest) & pending), (name, op, args)
+                pending |= _sgprs(dst)
+                checked += 1
+                continue
+            if op == "s_waitcnt" and "lgkmcnt(0)" in args:
+                pending = set()
+                continue
+            if pending:
+                assert not (_sgprs(args) & pending), (name, op, args, sorted(pending)[:4])
+    assert checked > 20, "expected the weight-streaming scalar loads"
+
+
+def test_dpp_reads_respect_the_valu_write_hazard(disassembly):
+    """gfx9 needs two wait states between a VALU write of a VGPR and a DPP read of it; the hazard
+    recogniser does not look inside inline asm (the guided filter's last scan step is a hand-placed
+    s_nop + v_add_u32_dpp run).  Checked for every DPP instruction of the library."""
+    seen = 0
+    for name, insts in disassembly.items():
+        recent = [set(), set()]                      # VGPRs written by the last two issue slots
+        for op, args in insts:
+            if op == "s_nop":
+                for _ in range(int(args.split()[0], 0) + 1):
+                    recent = [recent[1], set()]
+                continue
+            ops = [a.strip() for a in args.split(",")]
+            if "_dpp" in op or " row_" in args or "quad_perm" in args or "wave_" in args:
+                seen += 1
+                src0 = ops[1].split()[0] if len(ops) > 1 else ""
+                regs = set()
+                m = re.match(r"v\[(\d+):(\d+)\]", src0)
+                if m:
+                    regs = set(range(int(m.group(1)), int(m.group(2)) + 1))
+                elif re.match(r"v(\d+)$", src0):
+                    regs = {int(src0[1:])}
+                assert not (regs & (recent[0] | recent[1])), (name, op, args)
+            written = set()
+            if op.startswith("v_") and not op.startswith("v_cmp") and ops and ops[0]:
+                m = re.match(r"v\[(\d+):(\d+)\]", ops[0])
+                if m:
+                    written = set(range(int(m.group(1)), int(m.group(2)) + 1))
+                elif re.match(r"v(\d+)$", ops[0]):
+                    written = {int(ops[0][1:])}
+            recent = [recent[1], written]
+    assert seen > 50, "expected the DPP scans of the guided filter's stage 1"
+
+
 def test_argument_validation_needs_no_gpu(built):
     lib = _ffi.load_library()
     bufs = [ctypes.create_string_buffer(64 * 64 * 3) for _ in range(3)]
