@@ -16,10 +16,10 @@
 //            sum down the image starting 2r rows above the first output row.  Both are
 //            reproduced as sequential chains (one lane per row / per column), exposed to the
 //            GPU as parallelism over rows x planes x images, in two forms with identical bytes:
-//            radius 45 / 52 (the reference's parameter sets): gf_rowstate_kernel +
-//            gf_colwalk_kernel - the double row sums never reach HBM (see the comment block
-//            above them); any other radius <= 120: gf_rowsum_kernel + gf_colsum_apply_kernel,
-//            which write every row sum (8 B per pixel and plane) and read it twice.
+//            radius 1..96: gf_rowstate_kernel<R> + gf_colwalk_kernel<R> (rf_gf_fused.hpp,
+//            instantiated per radius in rf_gf_fused_inst.hip) - the double row sums never reach
+//            HBM; radius 97..120 and 0: gf_rowsum_kernel + gf_colsum_apply_kernel, which write
+//            every row sum (8 B per pixel and plane) and read it twice.
 //
 // Grey sources: the reference filters the CNN's grey `-r.png`, which imread turns into three
 // identical channels.  The src channels never mix, so identical channels give identical
