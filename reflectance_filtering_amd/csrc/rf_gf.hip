@@ -113,6 +113,46 @@ __device__ constexpr int sym(int i, int j)
 //                     the coefficients alpha_{s,g} (out[4s + g]) and beta_s (out[4s + 3]).
 constexpr int kGsFloats = kGsFloatsPublic;
 
+// out[i] = num[i] / den for six numerators, every quotient the correctly rounded IEEE result
+// (__fdiv_rn), i.e. what OpenCV's per-element division gives.  hipcc expands an IEEE division into
+// v_div_scale x 2, v_rcp, two FMAs that refine the reciprocal, a multiply, three FMAs, v_div_fmas
+// and v_div_fixup (46 issue cycles); the reciprocal and its refinement depend on the denominator
+// alone as long as v_div_scale leaves both operands unscaled, which it does whenever the
+// exponents are far from the float range's ends.  That case is recognised up front (|den| in
+// [2^-30, 2^50], every numerator zero or in [2^-40, 2^36]: no scaling, no denormal quotient) and
+// runs the SAME instruction sequence with the denominator's part done once; v_div_fixup stays,
+// it is what gives a zero numerator its sign.  Anything else takes the plain divisions.
+__device__ inline void div6_by(const float *num, float den, float *out)
+{
+    const uint32_t ud = __float_as_uint(den) & 0x7fffffffu;
+    uint32_t lo = 0xffffffffu, hi = 0u;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const uint32_t u = __float_as_uint(num[i]) & 0x7fffffffu;
+        lo = min(lo, u - 1u);  // zero wraps to the top: zero numerators are fine
+        hi = max(hi, u);
+    }
+    const bool fast = ud >= 0x30800000u && ud <= 0x58800000u &&  // 2^-30 .. 2^50
+                      lo >= 0x2b800000u - 1u && hi <= 0x51800000u;  // 2^-40 .. 2^36
+    if (fast) {
+        const float r0 = __builtin_amdgcn_rcpf(den);
+        const float e = __fmaf_rn(-den, r0, 1.0f);
+        const float r1 = __fmaf_rn(e, r0, r0);
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const float q0 = __fmul_rn(num[i], r1);
+            const float t = __fmaf_rn(-den, q0, num[i]);
+            const float q1 = __fmaf_rn(t, r1, q0);
+            const float t2 = __fmaf_rn(-den, q1, num[i]);
+            out[i] = __builtin_amdgcn_div_fixupf(__fmaf_rn(t2, r1, q1), den, num[i]);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+            out[i] = __fdiv_rn(num[i], den);
+    }
+}
+
 __device__ inline void gf_guide_algebra(const float *m, float eps_f, int eps_small, float *gs)
 {
     const float *mI = m;
@@ -143,9 +183,7 @@ __device__ inline void gf_guide_algebra(const float *m, float eps_f, int eps_sma
     gs[0] = mI[0];
     gs[1] = mI[1];
     gs[2] = mI[2];
-#pragma unroll
-    for (int e = 0; e < 6; e++)
-        gs[3 + e] = __fdiv_rn(inv[e], det);
+    div6_by(inv, det, gs + 3);
 }
 
 template <int SCN>
