@@ -364,7 +364,7 @@ __device__ __forceinline__ void fuse32(const float2v (&act)[32], const float *__
     // scalar FMAs spelled out: left to the SLP vectoriser the two chains become one v_pk_fma_f32
     // with the SGPR weight splat through op_sel_hi, the operand form tests/test_cabi.py bans
     // 
-#define RF_FUSE_FMA(Z, W, X) asm("v_fma_f32 %0, %1, %2, %0" : "+v"(Z) : "s"(W), "v"(X))
+#define RF_FUSE_FMA(Z, W, X) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(Z) : "s"(W), "v"(X))
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         RF_FUSE_FMA(z[0], w0[k], act[k].x);
