@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define RF_VERSION 101 /* 0.1.1 */
+#define RF_VERSION 102 /* 0.1.2 */
 
 /* return codes */
 #define RF_OK 0
@@ -108,6 +108,7 @@ int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, int n, int 
  *   srgb_lut   256 float32 on the device: linear value of each sRGB byte
  */
 #define RF_CNN_NPARAMS 4513
+#define RF_CNN_NPACKED 4673 /* floats of rf_cnn_pack_weights' output */
 int rf_cnn_reflectance_u8(const uint8_t *bgr, float *r_out, uint8_t *r_u8_out, int n, int h, int w,
                           const float *weights, const float *srgb_lut, void *stream);
 /*
@@ -119,8 +120,9 @@ int rf_cnn_reflectance_u8(const uint8_t *bgr, float *r_out, uint8_t *r_u8_out, i
  * with the packed copy in a small library-owned table keyed by (device, stream); its FIRST call on
  * a stream allocates and is therefore refused (RF_E_UNSUPPORTED) while that stream is captured.
  *   weights  4513 float32 on the device, layout as above
- *   packed   4513 float32 on the device, caller-owned: the weights in the order the kernel streams
- *            them (an opaque permutation; valid for this library version)
+ *   packed   RF_CNN_NPACKED float32 on the device, caller-owned: the weights in the order the
+ *            kernel streams them, the 160 fuse weights twice each (opaque; valid for this library
+ *            version)
  */
 int rf_cnn_pack_weights(const float *weights, float *packed, void *stream);
 int rf_cnn_reflectance_packed_u8(const uint8_t *bgr, float *r_out, uint8_t *r_u8_out, int n, int h,

@@ -19,6 +19,7 @@ JBF_TRUE_DIVISION = 1
 JBF_FORCE_GENERIC = 2
 JBF_GREY_AS_BGR = 4
 CNN_NPARAMS = 4513
+CNN_NPACKED = 4673          # RF_CNN_NPACKED: floats of rf_cnn_pack_weights' output
 
 EXPORTS = ("rf_version", "rf_last_error", "rf_shutdown", "rf_jbf_u8", "rf_gf_workspace_bytes",
            "rf_gf_u8", "rf_cnn_reflectance_u8", "rf_cnn_pack_weights",

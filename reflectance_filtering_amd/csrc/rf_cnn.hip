@@ -37,13 +37,15 @@ namespace {
 typedef float float2v __attribute__((ext_vector_type(2)));
 
 constexpr int kPxPerLane = 2;
-constexpr int kPackedFloats = 2 * 16 * 3 + 32 + 4 * (2 * 16 * 32 + 32) + 160 + 1;
+constexpr int kPackedFloats = 2 * 16 * 3 + 32 + 4 * (2 * 16 * 32 + 32) + 2 * 160 + 1;
+constexpr int kWfOff = 128 + 4 * 1056;  // the fuse weights' place in the packed stream
 constexpr int kRec = 66;  // floats per channel-pair record of a 32-input layer
 // packed layout (floats):
 //   [0, 96)          layer 0 pairs: for op in 0..15, k in 0..2: {W0[2op][k], W0[2op+1][k]}
 //   [96, 128)        b0
 //   then 4 x 16 records of 66 floats: k in 0..31: {W[2op][k], W[2op+1][k]}, then {b[2op], b[2op+1]}
-//   then wf[160], bf
+//   then the fuse weights twice each, {wf[k], wf[k]} (one 64-bit operand of a packed FMA that
+//   advances both pixels of a lane), then bf
 
 __global__ void cnn_pack_weights_kernel(const float *__restrict__ w, float *__restrict__ packed)
 {
@@ -58,8 +60,10 @@ __global__ void cnn_pack_weights_kernel(const float *__restrict__ w, float *__re
         const float *wl = w + 128 + l * 1056;
         const int op = q / kRec, rem = q % kRec, k = rem / 2, half = rem % 2;
         packed[t] = k < 32 ? wl[(2 * op + half) * 32 + k] : wl[1024 + 2 * op + half];
-    } else if (t < RF_CNN_NPARAMS) {
-        packed[t] = w[t];
+    } else if (t < kWfOff + 320) {
+        packed[t] = w[kWfOff + (t - kWfOff) / 2];
+    } else if (t < kPackedFloats) {
+        packed[t] = w[RF_CNN_NPARAMS - 1];
     }
 }
 
@@ -171,8 +175,8 @@ __device__ __forceinline__ void collect(float2v (*act)[kCnnThreads], const float
         const float2v v = act[k][lane];
         cur[0][k] = v.x;
         cur[1][k] = v.y;
-        z[0] = __fmaf_rn(wf32[k], v.x, z[0]);
-        z[1] = __fmaf_rn(wf32[k], v.y, z[1]);
+        z[0] = __fmaf_rn(wf32[2 * k], v.x, z[0]);
+        z[1] = __fmaf_rn(wf32[2 * k], v.y, z[1]);
     }
 }
 
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(kCnnThreads) void cnn_reflectance_kernel(
     for (int i = threadIdx.x; i < 256; i += kCnnThreads)
         lut[i] = srgb_lut[i];
     __syncthreads();
-    const float *wf = packed + 128 + 4 * 1056;
+    const float *wf = packed + kWfOff;
     const size_t stride = (size_t)gridDim.x * kCnnThreads;
     // lane handles pixels i and i + half (both halves stay coalesced)
     const size_t half = (npix + 1) / 2;
@@ -207,13 +211,13 @@ __global__ __launch_bounds__(kCnnThreads) void cnn_reflectance_kernel(
 #pragma unroll 1
         for (int l = 0; l < 4; l++) {
             layer32_pipelined(packed + 128 + l * 1056, cur, act);
-            collect(act, wf + 32 * (l + 1), cur, z);
+            collect(act, wf + 64 * (l + 1), cur, z);
         }
 #pragma unroll
         for (int p = 0; p < kPxPerLane; p++) {
             if (idx[p] >= npix)
                 continue;
-            const float zz = __fadd_rn(z[p], wf[160]);
+            const float zz = __fadd_rn(z[p], wf[320]);
             // caffe: 1. / (1. + exp(-x)) with a float exp; expf modelled as round(exp in double)
             const float e = (float)exp((double)(-zz));
             const float r = (float)(1.0 / (1.0 + (double)e));
@@ -265,6 +269,31 @@ __device__ __forceinline__ void finish_pair(const float2v &acc0, const float2v &
 #define RF_PKMUL_P1(ACC, W2, IN)                                                              \
     asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(ACC) : "s"(W2), "v"(IN))
 
+// Four k-steps of both pixels' chains (eight packed FMAs) as ONE asm statement.  hipcc's hazard
+// recogniser does not count an inline-asm statement as a wait state and assumes it may write
+// with a destination select, so between single-instruction statements of a dependent chain it
+// inserts an s_nop per k-step (944 of them in the two-layer loop body); inside a statement the
+// chain is the hardware's business (plain dependent VALU, interlocked).
+#define RF_PK4_BODY(OP0, OP1)                                                                 \
+    OP0 "v_pk_fma_f32 %0, %3, %7, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n"                      \
+        "v_pk_fma_f32 %1, %3, %7, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n"                      \
+        "v_pk_fma_f32 %0, %4, %8, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n"                      \
+        "v_pk_fma_f32 %1, %4, %8, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n"                      \
+        "v_pk_fma_f32 %0, %5, %9, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n"                      \
+        "v_pk_fma_f32 %1, %5, %9, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+#define RF_PKFMA4(ACC0, ACC1, WA, WB, WC, WD, IA, IB, IC, ID)                                 \
+    asm volatile(RF_PK4_BODY("v_pk_fma_f32 %0, %2, %6, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n" \
+                             "v_pk_fma_f32 %1, %2, %6, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n", \
+                             "")                                                              \
+                 : "+v"(ACC0), "+v"(ACC1)                                                     \
+                 : "s"(WA), "s"(WB), "s"(WC), "s"(WD), "v"(IA), "v"(IB), "v"(IC), "v"(ID))
+#define RF_PKMUL4(ACC0, ACC1, WA, WB, WC, WD, IA, IB, IC, ID)                                 \
+    asm volatile(RF_PK4_BODY("v_pk_mul_f32 %0, %2, %6 op_sel:[0,0] op_sel_hi:[1,0]\n"         \
+                             "v_pk_mul_f32 %1, %2, %6 op_sel:[0,1] op_sel_hi:[1,1]\n",        \
+                             "")                                                              \
+                 : "=&v"(ACC0), "=&v"(ACC1)                                                   \
+                 : "s"(WA), "s"(WB), "s"(WC), "s"(WD), "v"(IA), "v"(IB), "v"(IC), "v"(ID))
+
 // A 32-input layer: in[k] = {px0, px1} of input channel k, out[c] likewise.  rec = the layer's 16
 // records of kRec floats (buffer A: k = 0..15 of a channel pair, buffer B: k = 16..31 + biases).
 // Bias + ReLU of channel pair o (2 packed adds, 4 max: "simple" 2-cycle instructions) are spread
@@ -298,27 +327,28 @@ __device__ __forceinline__ void layer32_regs(const float *__restrict__ rec, cons
         if ((STEP) == 5)                                                                     \
             out[2 * (PO) + 1].y = fmaxf(tf1.y, 0.f);                                         \
     } while (0)
-    // 16 inputs of a pair; FIRST: the chain starts here; FIN0: first finish step placed in this half
+    // 16 inputs of a pair in four statements of four k-steps; FIRST: the chain starts here; FIN0:
+    // first finish step placed in this half (one after each of the first three statements)
+#define RF_W2(W, K) float2v{W[2 * (K)], W[2 * (K) + 1]}
 #define RF_FMA16R(ACC0, ACC1, W0, W1, KBASE, FIRST, DOFIN, FIN0, PO, PA0, PA1, PB)           \
-    _Pragma("unroll") for (int k = 0; k < 8; k++)                                            \
-    {                                                                                        \
-        const float2v w2 = float2v{W0[2 * k], W0[2 * k + 1]};                                \
-        if ((FIRST) && k == 0) {                                                             \
-            RF_PKMUL_P0(ACC0, w2, in[(KBASE) + k]);                                          \
-            RF_PKMUL_P1(ACC1, w2, in[(KBASE) + k]);                                          \
-        } else {                                                                             \
-            RF_PKFMA_P0(ACC0, w2, in[(KBASE) + k]);                                          \
-            RF_PKFMA_P1(ACC1, w2, in[(KBASE) + k]);                                          \
-        }                                                                                    \
-        if ((DOFIN) && (k == 2 || k == 4 || k == 6))                                         \
-            RF_FIN((FIN0) + (k - 2) / 2, PO, PA0, PA1, PB);                                  \
-    }                                                                                        \
-    _Pragma("unroll") for (int k = 0; k < 8; k++)                                            \
-    {                                                                                        \
-        const float2v w2 = float2v{W1[2 * k], W1[2 * k + 1]};                                \
-        RF_PKFMA_P0(ACC0, w2, in[(KBASE) + 8 + k]);                                          \
-        RF_PKFMA_P1(ACC1, w2, in[(KBASE) + 8 + k]);                                          \
-    }
+    if (FIRST)                                                                               \
+        RF_PKMUL4(ACC0, ACC1, RF_W2(W0, 0), RF_W2(W0, 1), RF_W2(W0, 2), RF_W2(W0, 3),        \
+                  in[(KBASE)], in[(KBASE) + 1], in[(KBASE) + 2], in[(KBASE) + 3]);           \
+    else                                                                                     \
+        RF_PKFMA4(ACC0, ACC1, RF_W2(W0, 0), RF_W2(W0, 1), RF_W2(W0, 2), RF_W2(W0, 3),        \
+                  in[(KBASE)], in[(KBASE) + 1], in[(KBASE) + 2], in[(KBASE) + 3]);           \
+    if (DOFIN)                                                                               \
+        RF_FIN((FIN0), PO, PA0, PA1, PB);                                                    \
+    RF_PKFMA4(ACC0, ACC1, RF_W2(W0, 4), RF_W2(W0, 5), RF_W2(W0, 6), RF_W2(W0, 7),            \
+              in[(KBASE) + 4], in[(KBASE) + 5], in[(KBASE) + 6], in[(KBASE) + 7]);           \
+    if (DOFIN)                                                                               \
+        RF_FIN((FIN0) + 1, PO, PA0, PA1, PB);                                                \
+    RF_PKFMA4(ACC0, ACC1, RF_W2(W1, 0), RF_W2(W1, 1), RF_W2(W1, 2), RF_W2(W1, 3),            \
+              in[(KBASE) + 8], in[(KBASE) + 9], in[(KBASE) + 10], in[(KBASE) + 11]);         \
+    if (DOFIN)                                                                               \
+        RF_FIN((FIN0) + 2, PO, PA0, PA1, PB);                                                \
+    RF_PKFMA4(ACC0, ACC1, RF_W2(W1, 4), RF_W2(W1, 5), RF_W2(W1, 6), RF_W2(W1, 7),            \
+              in[(KBASE) + 12], in[(KBASE) + 13], in[(KBASE) + 14], in[(KBASE) + 15]);
     RF_SLOAD16(a0, rec, 0);
     RF_SLOAD16(a1, rec, 64);
     // pair OP accumulates in CUR*, pair OP - 1 (PRV*) is finished meanwhile
@@ -348,34 +378,48 @@ __device__ __forceinline__ void layer32_regs(const float *__restrict__ rec, cons
     for (int st = 0; st < 6; st++)
         RF_FIN(st, 15, accO0, accO1, biasO);
 #undef RF_FMA16R
+#undef RF_W2
 #undef RF_FIN
 #undef RF_SLOAD2
 #undef RF_SLOAD16
 }
 
-// 32 terms of the fuse dot product for both pixels
-__device__ __forceinline__ void fuse32(const float2v (&act)[32], const float *__restrict__ wf32,
-                                       float (&z)[kPxPerLane])
+// 32 terms of the fuse dot product for both pixels: one packed FMA per term, its weight operand
+// the pair {wf[k], wf[k]} of the packed stream (no operand re-routing: an SGPR source with op_sel is
+// the form that is wrong on gfx950, DESIGN.md 3.3, which is why the stream holds these twice).
+// Eight terms per asm statement (see RF_PKFMA4 for why), volatile so that hipcc does not spread
+// them over the neighbouring layer and spill the SGPR file.
+__device__ __forceinline__ void fuse32(const float2v (&act)[32], const float *__restrict__ wf64,
+                                       float2v &z)
 {
-    float16v w0, w1;
-    asm volatile("s_load_dwordx16 %0, %1, 0" : "=s"(w0) : "s"(wf32));
-    asm volatile("s_load_dwordx16 %0, %1, 64" : "=s"(w1) : "s"(wf32));
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(w0), "+s"(w1));
-    // scalar FMAs spelled out: left to the SLP vectoriser the two chains become one v_pk_fma_f32
-    // with the SGPR weight splat through op_sel_hi, the operand form tests/test_cabi.py bans
-    // 
-#define RF_FUSE_FMA(Z, W, X) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(Z) : "s"(W), "v"(X))
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        RF_FUSE_FMA(z[0], w0[k], act[k].x);
-        RF_FUSE_FMA(z[1], w0[k], act[k].y);
-    }
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        RF_FUSE_FMA(z[0], w1[k], act[16 + k].x);
-        RF_FUSE_FMA(z[1], w1[k], act[16 + k].y);
-    }
-#undef RF_FUSE_FMA
+    float16v w0, w1, w2, w3;
+    asm volatile("s_load_dwordx16 %0, %1, 0" : "=s"(w0) : "s"(wf64));
+    asm volatile("s_load_dwordx16 %0, %1, 64" : "=s"(w1) : "s"(wf64));
+    asm volatile("s_load_dwordx16 %0, %1, 128" : "=s"(w2) : "s"(wf64));
+    asm volatile("s_load_dwordx16 %0, %1, 192" : "=s"(w3) : "s"(wf64));
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(w0), "+s"(w1), "+s"(w2), "+s"(w3));
+#define RF_W2(W, K) float2v{W[2 * (K)], W[2 * (K) + 1]}
+#define RF_FUSE8(W, KBASE)                                                                    \
+    asm volatile("v_pk_fma_f32 %0, %1, %9, %0\n"                                              \
+                 "v_pk_fma_f32 %0, %2, %10, %0\n"                                             \
+                 "v_pk_fma_f32 %0, %3, %11, %0\n"                                             \
+                 "v_pk_fma_f32 %0, %4, %12, %0\n"                                             \
+                 "v_pk_fma_f32 %0, %5, %13, %0\n"                                             \
+                 "v_pk_fma_f32 %0, %6, %14, %0\n"                                             \
+                 "v_pk_fma_f32 %0, %7, %15, %0\n"                                             \
+                 "v_pk_fma_f32 %0, %8, %16, %0"                                               \
+                 : "+v"(z)                                                                    \
+                 : "s"(RF_W2(W, 0)), "s"(RF_W2(W, 1)), "s"(RF_W2(W, 2)), "s"(RF_W2(W, 3)),    \
+                   "s"(RF_W2(W, 4)), "s"(RF_W2(W, 5)), "s"(RF_W2(W, 6)), "s"(RF_W2(W, 7)),    \
+                   "v"(act[(KBASE)]), "v"(act[(KBASE) + 1]), "v"(act[(KBASE) + 2]),           \
+                   "v"(act[(KBASE) + 3]), "v"(act[(KBASE) + 4]), "v"(act[(KBASE) + 5]),       \
+                   "v"(act[(KBASE) + 6]), "v"(act[(KBASE) + 7]))
+    RF_FUSE8(w0, 0);
+    RF_FUSE8(w1, 8);
+    RF_FUSE8(w2, 16);
+    RF_FUSE8(w3, 24);
+#undef RF_FUSE8
+#undef RF_W2
 }
 
 __global__ __launch_bounds__(kCnnThreads) void cnn_reflectance_regs_kernel(
@@ -386,7 +430,7 @@ __global__ __launch_bounds__(kCnnThreads) void cnn_reflectance_regs_kernel(
     for (int i = threadIdx.x; i < 256; i += kCnnThreads)
         lut[i] = srgb_lut[i];
     __syncthreads();
-    const float *wf = packed + 128 + 4 * 1056;
+    const float *wf = packed + kWfOff;
     const size_t stride = (size_t)gridDim.x * kCnnThreads;
     const size_t half = (npix + 1) / 2;  // lane handles pixels i and i + half (both stay coalesced)
     for (size_t i = (size_t)blockIdx.x * kCnnThreads + threadIdx.x; i < half; i += stride) {
@@ -400,7 +444,7 @@ __global__ __launch_bounds__(kCnnThreads) void cnn_reflectance_regs_kernel(
             x[2] = float2v{lut[p0[0]], lut[p1[0]]};
         }
         float2v A[32], B[32];
-        float z[kPxPerLane] = {0.f, 0.f};
+        float2v z = float2v{0.f, 0.f};  // the fuse dot product of {pixel 0, pixel 1}
         // layer 0: 16 channel pairs x 3 inputs, weights {W0[2o][k], W0[2o+1][k]} at packed[6 o + 2 k],
         // biases at packed[96 + c]; two halves of 8 pairs, each with its own explicit scalar loads
 #pragma unroll
@@ -433,15 +477,15 @@ __global__ __launch_bounds__(kCnnThreads) void cnn_reflectance_regs_kernel(
 #pragma unroll 1
         for (int l = 0; l < 4; l += 2) {
             layer32_regs(packed + 128 + l * 1056, A, B);
-            fuse32(B, wf + 32 * (l + 1), z);
+            fuse32(B, wf + 64 * (l + 1), z);
             layer32_regs(packed + 128 + (l + 1) * 1056, B, A);
-            fuse32(A, wf + 32 * (l + 2), z);
+            fuse32(A, wf + 64 * (l + 2), z);
         }
 #pragma unroll
         for (int p = 0; p < kPxPerLane; p++) {
             if (idx[p] >= npix)
                 continue;
-            const float zz = __fadd_rn(z[p], wf[160]);
+            const float zz = __fadd_rn(p == 0 ? z.x : z.y, wf[320]);
             // caffe: 1. / (1. + exp(-x)) with a float exp; expf modelled as round(exp in double)
             const float e = (float)exp((double)(-zz));
             const float r = (float)(1.0 / (1.0 + (double)e));
@@ -456,6 +500,9 @@ __global__ __launch_bounds__(kCnnThreads) void cnn_reflectance_regs_kernel(
 #undef RF_PKFMA_P1
 #undef RF_PKMUL_P0
 #undef RF_PKMUL_P1
+#undef RF_PKFMA4
+#undef RF_PKMUL4
+#undef RF_PK4_BODY
 
 // rf_cnn_reflectance_u8 (raw weights) keeps one packed copy per (device, stream): a call re-packs
 // the caller's weights on its own stream (18 tiny workgroups; the weights may have changed since
@@ -582,13 +629,13 @@ void cnn_shutdown()
 extern "C" int rf_cnn_pack_weights(const float *weights, float *packed, void *stream_)
 {
     using namespace rf;
-    static_assert(kPackedFloats == RF_CNN_NPARAMS, "packed layout is a permutation");
+    static_assert(kPackedFloats == RF_CNN_NPACKED, "the size the header promises");
     if (!weights || !packed)
         return fail(RF_E_BADARG, "rf_cnn_pack_weights: NULL pointer");
     if (ranges_overlap(weights, sizeof(float) * RF_CNN_NPARAMS, packed,
-                       sizeof(float) * RF_CNN_NPARAMS))
+                       sizeof(float) * RF_CNN_NPACKED))
         return fail(RF_E_BADARG, "rf_cnn_pack_weights: packed must not overlap weights");
-    hipLaunchKernelGGL(cnn_pack_weights_kernel, dim3((RF_CNN_NPARAMS + 255) / 256), dim3(256), 0,
+    hipLaunchKernelGGL(cnn_pack_weights_kernel, dim3((RF_CNN_NPACKED + 255) / 256), dim3(256), 0,
                        (hipStream_t)stream_, weights, packed);
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;
@@ -625,7 +672,7 @@ extern "C" int rf_cnn_reflectance_u8(const uint8_t *bgr, float *r_out, uint8_t *
     if (rc != RF_OK)
         return rc;
     // (the packed copy is rebuilt on the caller's stream every call: the weights may have changed)
-    hipLaunchKernelGGL(cnn_pack_weights_kernel, dim3((RF_CNN_NPARAMS + 255) / 256), dim3(256), 0,
+    hipLaunchKernelGGL(cnn_pack_weights_kernel, dim3((RF_CNN_NPACKED + 255) / 256), dim3(256), 0,
                        stream, weights, packed);
     return launch_forward(bgr, r_out, r_u8_out, n, h, w, packed, srgb_lut, stream);
 }

@@ -107,7 +107,7 @@ def _cnn_device_consts(torch, device, weights):
 
     def pack(w_host):
         raw = torch.from_numpy(w_host).to(device)
-        packed = torch.empty_like(raw)
+        packed = torch.empty(_ffi.CNN_NPACKED, dtype=torch.float32, device=device)
         _ffi.check(lib.rf_cnn_pack_weights(raw.data_ptr(), packed.data_ptr(),
                                            _ffi.current_stream_ptr(torch)), "rf_cnn_pack_weights")
         return packed                       # `raw` may go: the pack is ordered on this stream
