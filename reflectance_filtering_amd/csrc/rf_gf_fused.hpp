@@ -401,9 +401,18 @@ __global__ __launch_bounds__(128, (R <= 64 ? 2 : 1)) void gf_colwalk_kernel(
     auto fetch = [&](int slot) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NL; i++) {
-            const uint32_t ro = L.rowoff[slot][min(4 * i + r4, T - 1)];
+            // (timing experiments of tools/gf_stamp_build.py, results WRONG: RF_GF_EXP_ALIAS makes
+            //  the leaving operand the entering one - half the distinct cache lines -, RF_GF_EXP_HOT
+            //  also takes every row from image row 0 - no memory traffic to speak of)
+#if defined(RF_GF_EXP_HOT)
+            const uint32_t ro = 0, ol_ = oe;
+#elif defined(RF_GF_EXP_ALIAS)
+            const uint32_t ro = L.rowoff[slot][min(4 * i + r4, T - 1)], ol_ = oe;
+#else
+            const uint32_t ro = L.rowoff[slot][min(4 * i + r4, T - 1)], ol_ = ol;
+#endif
             pe[i] = *reinterpret_cast<const float4 *>(abgb + (oe + ro));
-            pl[i] = *reinterpret_cast<const float4 *>(abgb + (ol + ro));
+            pl[i] = *reinterpret_cast<const float4 *>(abgb + (ol_ + ro));
         }
         if (chain)
             pst = Ps[L.rowtab[slot][cl]];

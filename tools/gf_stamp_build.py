@@ -8,6 +8,10 @@ product library is untouched).  The stamps are summed over waves in a device buf
 
     make -C reflectance_filtering_amd/csrc && python tools/gf_stamp_build.py [radius] \
         && gpurun -- python3 tools/gf_stamp_run.py [radius]
+
+RF_STAMP_DEFS adds compiler flags (the experiment switches of rf_gf_fused.hpp: -DRF_GF_EXP_ALIAS,
+-DRF_GF_EXP_HOT - operand fetches that hit in cache, results wrong, timing only), RF_STAMP_SUFFIX
+names the library (librf_hip.so.stamp<suffix>; gf_stamp_run.py reads the same variable).
 """
 import os
 import subprocess
@@ -39,10 +43,12 @@ with open(path, "w") as fh:
 obj = os.path.join(CSRC, "_gf_stamp_tmp.o")
 flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-gpu-rdc",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+flags += os.environ.get("RF_STAMP_DEFS", "").split()   # experiment switches of rf_gf_fused.hpp
 subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["-c", path, "-o", obj])
 objs = [os.path.join(CSRC, o) for o in ("rf_api.o", "rf_jbf.o", "rf_gf.o", "rf_cnn.o",
                                         "rf_colorize.o", "rf_whdr.o")]
-out = os.path.join(ROOT, "reflectance_filtering_amd", "librf_hip.so.stamp")
+out = os.path.join(ROOT, "reflectance_filtering_amd",
+                   "librf_hip.so.stamp" + os.environ.get("RF_STAMP_SUFFIX", ""))
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out,
                        obj] + objs)
 os.remove(path)

@@ -17,7 +17,8 @@ import reflectance_filtering_amd as rf
 radius = int(sys.argv[1]) if len(sys.argv) > 1 else 45
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 kind = sys.argv[3] if len(sys.argv) > 3 else "grey"
-rf._ffi.LIB_PATH = os.path.join(ROOT, "reflectance_filtering_amd", "librf_hip.so.stamp")
+rf._ffi.LIB_PATH = os.path.join(ROOT, "reflectance_filtering_amd",
+                                "librf_hip.so.stamp" + os.environ.get("RF_STAMP_SUFFIX", ""))
 lib = rf._ffi.load_library()
 lib.rf_debug_option(b"gf_one_stream", 1)
 torch.cuda.set_device(0)
