@@ -69,6 +69,12 @@ def parse_args(argv=None):
                          "image (profiling the colour tap loop; named in config.workload)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="target CPU time of the cpu_baseline sample (0 disables it)")
+    ap.add_argument("--traffic", choices=("auto", "live", "profile", "off"), default="auto",
+                    help="roofline.traffic of the metric launch: 'live' measures it now (two child "
+                         "runs of this script under rocprofv3 --pmc, FETCH_SIZE and WRITE_SIZE "
+                         "in separate passes), 'profile' takes the committed summary of the same "
+                         "launch shape, 'auto' = live on one GPU when rocprofv3 is there and this "
+                         "process is not itself being profiled, else profile; 'off' = null")
     ap.add_argument("--no-extras", "--no-colour-src", dest="no_extras", action="store_true",
                     help="skip the secondary launches and the C2/C3/C5 lines (keeps a profile of "
                          "this command to the one timed kernel shape)")
@@ -430,6 +436,78 @@ def committed_traffic(n, h, w):
     return None, None
 
 
+def being_profiled():
+    """True when this process runs under a rocprofiler tool (its own PMC passes must not nest)."""
+    env = os.environ
+    return any(k in env for k in ("ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD",
+                                  "ROCPROF_OUTPUT_PATH")) or "rocprofiler" in env.get("LD_PRELOAD", "")
+
+
+def parse_counter_csv(path, counter, match="jbf"):
+    """Per-dispatch values of `counter` for the kernels whose name contains `match`, from a
+    rocprofv3 *_counter_collection.csv."""
+    import csv
+    vals = {}
+    with open(path, newline="") as fh:
+        for r in csv.DictReader(fh):
+            if r.get("Counter_Name") == counter and match in r.get("Kernel_Name", ""):
+                key = int(r["Dispatch_Id"])
+                vals[key] = vals.get(key, 0.0) + float(r["Counter_Value"])
+    return [vals[k] for k in sorted(vals)]
+
+
+def live_traffic(args, n, h, w, deadline_s=150.0):
+    """HBM-side bytes of ONE launch of the metric kernel, measured now: this script is run twice
+    as a child under `rocprofv3 --pmc` (FETCH_SIZE, then WRITE_SIZE - separate passes, as
+    MI355X_MICROARCH.md's HBM section prescribes; no trace domain beside --kernel-trace), one
+    warm-up and one timed launch of the same shape each.  Units and corrections of that guide:
+    both counters are in KiB; on gfx950 FETCH_SIZE tallies 128-byte requests as 64 bytes, so it
+    is doubled (tools/microbench/fetch_calib.hip measures 2.000 for this kernel's load widths).
+    Returns (bytes per launch, source text) or (None, reason)."""
+    import glob
+    import shutil
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="rf_bench_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", RF_BENCH_CHILD="1")
+    for key in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(key, None)
+    got = {}
+    t_end = time.time() + deadline_s
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out_dir = os.path.join(tmp, counter.lower())
+            cmd = [prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out_dir,
+                   "--", sys.executable, os.path.abspath(__file__), "--config", args.config,
+                   "--batch", str(n), "--height", str(h), "--width", str(w),
+                   "--sigma-color", repr(args.sigma_color), "--sigma-spatial",
+                   repr(args.sigma_spatial), "--src", args.src, "--steps", "1", "--warmup", "1",
+                   "--cpu-seconds", "0", "--no-extras", "--traffic", "off"]
+            left = t_end - time.time()
+            if left < 20:
+                return None, "no time left for the %s pass" % counter
+            try:
+                p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE,
+                                   stderr=subprocess.PIPE, timeout=left)
+            except subprocess.TimeoutExpired:
+                return None, "the %s pass exceeded its time" % counter
+            files = glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True)
+            if p.returncode != 0 or not files:
+                return None, "the %s pass failed (rc %d)" % (counter, p.returncode)
+            vals = parse_counter_csv(files[0], counter)
+            if not vals:
+                return None, "no %s row for the kernel" % counter
+            got[counter] = vals[-1] * 1024.0          # the timed launch (the last one), KiB -> B
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    total = 2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"]
+    return total, ("measured by this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of "
+                   "this launch shape (FETCH_SIZE %.0f B raw, doubled for gfx950; WRITE_SIZE %.0f B)"
+                   % (got["FETCH_SIZE"], got["WRITE_SIZE"]))
+
+
 def run_rank(args):
     stub = os.environ.get("RF_BENCH_STUB") == "1"
     if stub and os.environ.get("RF_BENCH_STUB_FAIL_RANK") == os.environ.get("RANK", "0"):
@@ -555,11 +633,22 @@ def run_rank(args):
     }
     if not stub:
         achieved = launch_px * wl.bytes_per_px / (kernel_ms * 1e-3) / 1e9
-        traffic, source = committed_traffic(n, h, w) if kind == "jbf" else (None, None)
+        traffic, source = None, None
+        mode = args.traffic
+        if kind == "jbf" and mode != "off":
+            if mode == "live" or (mode == "auto" and world == 1 and not being_profiled()
+                                  and os.environ.get("RF_BENCH_CHILD") != "1"):
+                traffic, source = live_traffic(args, n, h, w)
+                if traffic is None:
+                    sys.stderr.write("bench.py: live traffic measurement unavailable: %s\n" % source)
+            if traffic is None:
+                traffic, source = committed_traffic(n, h, w)
+                if source:
+                    source += (" (rocprofv3 --pmc passes of this launch shape; not measured by "
+                               "this run)")
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                           "traffic_source": (source + " (rocprofv3 --pmc passes of this launch "
-                                              "shape; not measured by this run)") if source else None,
+                           "traffic_source": source,
                            "kernel_note": "the launch is timed through HIP events on its stream, "
                                           "not identified by name; profiles/ lists the kernels of "
                                           "the same command under rocprofv3",

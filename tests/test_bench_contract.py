@@ -102,3 +102,30 @@ def test_scale_report_tabulates_the_curve(tmp_path, monkeypatch):
     assert doc["curve"][0]["ratio_to_one_gpu"] == 1.0
     assert 1.5 < doc["curve"][1]["ratio_to_one_gpu"] < 2.2       # the stub step is a fixed sleep
     assert out.exists()
+
+
+def test_live_traffic_helpers(tmp_path, monkeypatch):
+    """The pieces of bench.py's live PMC measurement that run without a GPU: the counter CSV reader
+    (the timed launch is the LAST dispatch of the kernel; other kernels and counters are ignored)
+    and the guard that keeps a profiled run from starting profiler passes of its own."""
+    csv_path = tmp_path / "1_counter_collection.csv"
+    head = ('"Correlation_Id","Dispatch_Id","Agent_Id","Queue_Id","Process_Id","Thread_Id",'
+            '"Grid_Size","Kernel_Id","Kernel_Name","Workgroup_Size","LDS_Block_Size","Scratch_Size",'
+            '"VGPR_Count","Accum_VGPR_Count","SGPR_Count","Counter_Name","Counter_Value",'
+            '"Start_Timestamp","End_Timestamp"\n')
+    row = '%d,%d,"Agent 2",1,9,9,64,3,"%s",256,0,0,4,0,16,"%s",%f,1,2\n'
+    body = (row % (1, 1, "void at::native::fill(float)", "FETCH_SIZE", 15.5)
+            + row % (2, 2, "void rf::(anonymous namespace)::jbf_tile64_kernel<1, 8>(...)", "FETCH_SIZE", 100.0)
+            + row % (3, 3, "void rf::(anonymous namespace)::jbf_tile64_kernel<1, 8>(...)", "FETCH_SIZE", 200.0)
+            + row % (3, 3, "void rf::(anonymous namespace)::jbf_tile64_kernel<1, 8>(...)", "WRITE_SIZE", 7.0))
+    csv_path.write_text(head + body)
+    assert bench.parse_counter_csv(str(csv_path), "FETCH_SIZE") == [100.0, 200.0]
+    assert bench.parse_counter_csv(str(csv_path), "WRITE_SIZE") == [7.0]
+    assert bench.parse_counter_csv(str(csv_path), "FETCH_SIZE", match="nothing") == []
+    for key in ("ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "ROCPROF_OUTPUT_PATH",
+                "LD_PRELOAD"):
+        monkeypatch.delenv(key, raising=False)
+    assert not bench.being_profiled()
+    monkeypatch.setenv("ROCP_TOOL_LIBRARIES", "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so")
+    assert bench.being_profiled()
+    assert bench.parse_args([]).traffic == "auto"
