@@ -453,6 +453,7 @@ def parse_counter_csv(path, counter, match="jbf"):
             if r.get("Counter_Name") == counter and match in r.get("Kernel_Name", ""):
                 key = int(r["Dispatch_Id"])
                 vals[key] = vals.get(key, 0.0) + float(r["Counter_Value"])
+                parse_counter_csv.last_kernel = r["Kernel_Name"]
     return [vals[k] for k in sorted(vals)]
 
 
@@ -503,6 +504,8 @@ def live_traffic(args, n, h, w, deadline_s=150.0):
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     total = 2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"]
+    name = getattr(parse_counter_csv, "last_kernel", "")
+    live_traffic.kernel = name[:name.index(">(") + 1] if ">(" in name else name.split("(")[0]
     return total, ("measured by this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of "
                    "this launch shape (FETCH_SIZE %.0f B raw, doubled for gfx950; WRITE_SIZE %.0f B)"
                    % (got["FETCH_SIZE"], got["WRITE_SIZE"]))
@@ -649,9 +652,11 @@ def run_rank(args):
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                            "traffic_source": source,
-                           "kernel_note": "the launch is timed through HIP events on its stream, "
-                                          "not identified by name; profiles/ lists the kernels of "
-                                          "the same command under rocprofv3",
+                           "kernel": getattr(live_traffic, "kernel", None),
+                           "kernel_note": "the launch is timed through HIP events on its stream; "
+                                          "'kernel' is the name rocprofv3 gave the launch in the "
+                                          "live --pmc pass (null without one); profiles/ lists "
+                                          "the kernels of the same command under rocprofv3",
                            "kernel_ms": kernel_ms,
                            "algorithmic_bytes_per_launch": launch_px * wl.bytes_per_px}
     if kind == "jbf" and not stub:
