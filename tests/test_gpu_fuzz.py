@@ -1,7 +1,9 @@
 """GPU suite: seeded random cases against the ORACLE (not against another kernel), sized so that
 the C oracle answers in milliseconds - every radius of the fused guided filter (1..96) and beyond,
 every border type, channel combination and flag of the joint bilateral, chained passes, batches
-that mix grey and colour images.  Bounded by time: `RF_FUZZ_SECONDS` (default 40) per test.
+that mix grey and colour images, the CNN with the shipped and with random weights.  Bounded by
+time: `RF_FUZZ_SECONDS` (default 40) per filter test; `RF_FUZZ_SEED` (default 0) offsets the seeds
+for longer runs on other cases.
 """
 import os
 import time
@@ -12,6 +14,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 SECONDS = float(os.environ.get("RF_FUZZ_SECONDS", "40"))
+SEED = int(os.environ.get("RF_FUZZ_SEED", "0"))
 
 
 @pytest.fixture(scope="module")
@@ -43,7 +46,7 @@ def _image(rng, h, w, c, kind):
 
 def test_guided_filter_random_cases_match_the_oracle(env):
     rf, co, torch = env
-    rng = np.random.default_rng(2024)
+    rng = np.random.default_rng(2024 + SEED)
     t_end = time.time() + SECONDS
     cases = 0
     while time.time() < t_end or cases < 12:
@@ -74,7 +77,7 @@ def test_guided_filter_random_cases_match_the_oracle(env):
 
 def test_joint_bilateral_random_cases_match_the_oracle(env):
     rf, co, torch = env
-    rng = np.random.default_rng(4048)
+    rng = np.random.default_rng(4048 + SEED)
     t_end = time.time() + SECONDS
     cases = 0
     while time.time() < t_end or cases < 12:
@@ -93,3 +96,36 @@ def test_joint_bilateral_random_cases_match_the_oracle(env):
         assert np.array_equal(got, want), (cases, h, w, jcn, scn, sc, ss, d, border)
         cases += 1
     print("joint-bilateral fuzz: %d cases" % cases)
+
+
+def test_cnn_random_cases_match_the_oracle(env):
+    """Random image sizes (odd pixel counts: the kernel pairs pixel i with pixel i + half), image
+    statistics and - every other case - random weights of the magnitude of the shipped ones:
+    float output within 2e-7 of the oracle (the contract of test_cnn_matches_oracle_and_golden),
+    bytes within one count on < 1e-4 of the pixels."""
+    rf, co, torch = env
+    rng = np.random.default_rng(777 + SEED)
+    shipped = rf.weights.load_weights()
+    t_end = time.time() + SECONDS / 4
+    cases = 0
+    worst = 0.0
+    while time.time() < t_end or cases < 6:
+        h, w = int(rng.integers(1, 90)), int(rng.integers(1, 130))
+        n = int(rng.integers(1, 4))
+        imgs = np.stack([_image(rng, h, w, 3, int(rng.integers(0, 4))) for _ in range(n)])
+        if cases % 2:
+            wts = (shipped * rng.uniform(0.5, 1.5, shipped.shape)
+                   + rng.normal(0, 0.02, shipped.shape)).astype(np.float32)
+        else:
+            wts = shipped
+        r, r8 = rf.ops.cnn_reflectance_u8(torch.from_numpy(imgs).cuda(), weights=wts)
+        r, r8 = r.cpu().numpy(), r8.cpu().numpy()
+        for i in range(n):
+            want_r, want_r8 = co.cnn_reflectance(imgs[i], wts)
+            err = float(np.abs(r[i] - want_r).max())
+            worst = max(worst, err)
+            assert err <= 2e-7, (cases, h, w, i, err)
+            d8 = np.abs(r8[i].astype(int) - want_r8.astype(int))
+            assert d8.max() <= 1 and np.mean(d8 != 0) < 1e-4 + 1.0 / d8.size, (cases, h, w, i)
+        cases += 1
+    print("CNN fuzz: %d cases, largest |r - oracle| %.3g" % (cases, worst))
