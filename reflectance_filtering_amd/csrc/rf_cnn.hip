@@ -592,8 +592,12 @@ int launch_forward(const uint8_t *bgr, float *r_out, uint8_t *r_u8_out, int n, i
 {
     const size_t npix = (size_t)n * h * w;
     size_t blocks = ((npix + 1) / 2 + kCnnThreads - 1) / kCnnThreads;
-    if (blocks > 256 * 20)
-        blocks = 256 * 20;
+    // grid-stride loop over at most 128 workgroups per CU: a grid that just fills the chip (6 per
+    // CU) is 8 % slower than 20 per CU, 80-160 per CU another 1.5 % faster (workgroups that end at
+    // different times keep the SIMDs' waves out of phase); one iteration per workgroup pays the
+    // sRGB table's load every time
+    if (blocks > 256 * 128)
+        blocks = 256 * 128;
     if (debug_get(kDbgCnnLdsColumns))  // cross-check: the LDS-column form of round 1
         hipLaunchKernelGGL(cnn_reflectance_kernel, dim3((unsigned)blocks), dim3(kCnnThreads), 0,
                            stream, bgr, r_out, r_u8_out, npix, packed, srgb_lut);
