@@ -13,5 +13,6 @@ python tools/stress_sizes.py > $O/r03_stress_sizes.json 2> $O/r03_stress.err
 python3 tools/gf_stamp_run.py 45 8 grey > $O/r03_gf_stamps_grey.json 2>/dev/null
 python3 tools/gf_stamp_run.py 45 8 colour > $O/r03_gf_stamps_colour.json 2>/dev/null
 python3 tools/cnn_cmp.py > $O/r03_cnn_cmp.txt 2>&1
-cp profiles/r03_* profiles/jbf_pmc_traffic.json $O/ 2>/dev/null
+# the summaries make_profiles*.py wrote into profiles/ on this box; -n: never over a fresh output above
+cp -n profiles/r03_* profiles/jbf_pmc_traffic.json $O/ 2>/dev/null
 ls $O | grep r03 | head -50
