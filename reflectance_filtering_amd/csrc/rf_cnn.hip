@@ -262,35 +262,28 @@ __device__ __forceinline__ void finish_pair(const float2v &acc0, const float2v &
     out_odd = float2v{fmaxf(__fadd_rn(acc0.y, by), 0.f), fmaxf(__fadd_rn(acc1.y, by), 0.f)};
 }
 
-// first term of a chain: fma(w, x, +0) == w * x (the product rounded once), so the chain starts
-// with a packed multiply and the accumulators need no zeroing
-#define RF_PKMUL_P0(ACC, W2, IN)                                                              \
-    asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(ACC) : "s"(W2), "v"(IN))
-#define RF_PKMUL_P1(ACC, W2, IN)                                                              \
-    asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(ACC) : "s"(W2), "v"(IN))
-
 // Four k-steps of both pixels' chains (eight packed FMAs) as ONE asm statement.  hipcc's hazard
 // recogniser does not count an inline-asm statement as a wait state and assumes it may write
 // with a destination select, so between single-instruction statements of a dependent chain it
 // inserts an s_nop per k-step (944 of them in the two-layer loop body); inside a statement the
 // chain is the hardware's business (plain dependent VALU, interlocked).
-#define RF_PK4_BODY(OP0, OP1)                                                                 \
-    OP0 "v_pk_fma_f32 %0, %3, %7, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n"                      \
-        "v_pk_fma_f32 %1, %3, %7, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n"                      \
-        "v_pk_fma_f32 %0, %4, %8, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n"                      \
-        "v_pk_fma_f32 %1, %4, %8, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n"                      \
-        "v_pk_fma_f32 %0, %5, %9, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n"                      \
-        "v_pk_fma_f32 %1, %5, %9, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+// k-steps 1..3 of a statement (operands: %0 %1 accumulators, %2..%5 weight pairs, %6..%9 inputs)
+#define RF_PK4_TAIL                                                                           \
+    "v_pk_fma_f32 %0, %3, %7, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n"                          \
+    "v_pk_fma_f32 %1, %3, %7, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n"                          \
+    "v_pk_fma_f32 %0, %4, %8, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n"                          \
+    "v_pk_fma_f32 %1, %4, %8, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n"                          \
+    "v_pk_fma_f32 %0, %5, %9, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n"                          \
+    "v_pk_fma_f32 %1, %5, %9, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
 #define RF_PKFMA4(ACC0, ACC1, WA, WB, WC, WD, IA, IB, IC, ID)                                 \
-    asm volatile(RF_PK4_BODY("v_pk_fma_f32 %0, %2, %6, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n" \
-                             "v_pk_fma_f32 %1, %2, %6, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n", \
-                             "")                                                              \
+    asm volatile("v_pk_fma_f32 %0, %2, %6, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n"             \
+                 "v_pk_fma_f32 %1, %2, %6, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n" RF_PK4_TAIL \
                  : "+v"(ACC0), "+v"(ACC1)                                                     \
                  : "s"(WA), "s"(WB), "s"(WC), "s"(WD), "v"(IA), "v"(IB), "v"(IC), "v"(ID))
+// the first four k-steps of a chain: fma(w, x, +0) == w * x, so it starts with a packed multiply
 #define RF_PKMUL4(ACC0, ACC1, WA, WB, WC, WD, IA, IB, IC, ID)                                 \
-    asm volatile(RF_PK4_BODY("v_pk_mul_f32 %0, %2, %6 op_sel:[0,0] op_sel_hi:[1,0]\n"         \
-                             "v_pk_mul_f32 %1, %2, %6 op_sel:[0,1] op_sel_hi:[1,1]\n",        \
-                             "")                                                              \
+    asm volatile("v_pk_mul_f32 %0, %2, %6 op_sel:[0,0] op_sel_hi:[1,0]\n"                     \
+                 "v_pk_mul_f32 %1, %2, %6 op_sel:[0,1] op_sel_hi:[1,1]\n" RF_PK4_TAIL         \
                  : "=&v"(ACC0), "=&v"(ACC1)                                                   \
                  : "s"(WA), "s"(WB), "s"(WC), "s"(WD), "v"(IA), "v"(IB), "v"(IC), "v"(ID))
 
@@ -498,11 +491,9 @@ __global__ __launch_bounds__(kCnnThreads) void cnn_reflectance_regs_kernel(
 }
 #undef RF_PKFMA_P0
 #undef RF_PKFMA_P1
-#undef RF_PKMUL_P0
-#undef RF_PKMUL_P1
 #undef RF_PKFMA4
 #undef RF_PKMUL4
-#undef RF_PK4_BODY
+#undef RF_PK4_TAIL
 
 // rf_cnn_reflectance_u8 (raw weights) keeps one packed copy per (device, stream): a call re-packs
 // the caller's weights on its own stream (18 tiny workgroups; the weights may have changed since
