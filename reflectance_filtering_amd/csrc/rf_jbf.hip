@@ -1732,44 +1732,53 @@ __global__ __launch_bounds__(16 * f32_tile_h(JCN, SCN)) void jbf_f32_quad_kernel
         const float *wrow = sw_s + (i < 0 ? -i : i) * sw_len + (r4 + 8);  // wrow[j], zero off the disk
         // weights of outputs 0..3 at column step c are wrow[c], wrow[c-1], wrow[c-2], wrow[c-3]
         float w0 = wrow[-hw4], w1 = wrow[-hw4 - 1], w2 = wrow[-hw4 - 2], w3 = wrow[-hw4 - 3];
-        for (int c = -hw4; c <= hw4 + 3; c++) {
-            const int xx = interior ? x0 + c : border_interpolate(x0 + c, w, border);
-            float jt[JCN], st[SCN];
+        // four columns per iteration (the span -hw4 .. hw4+3 is a multiple of four): their texel
+        // loads are issued together, so four columns' worth of vector-cache latency overlap
+        for (int c4 = -hw4; c4 <= hw4; c4 += 4) {
+            float jt[4][JCN], st[4][SCN], wn[4];
 #pragma unroll
-            for (int ch = 0; ch < JCN; ch++)
-                jt[ch] = jrow[(size_t)xx * JCN + ch];
-#pragma unroll
-            for (int ch = 0; ch < SCN; ch++)
-                st[ch] = srow[(size_t)xx * SCN + ch];
-            const float wnext = wrow[c + 1];
-            const float ws[4] = {w0, w1, w2, w3};
-#pragma unroll
-            for (int p = 0; p < 4; p++) {
-                // columns of the span that lie off output p's disk are not taps of p: OpenCV never
-                // reads them, so a NaN / Inf texel there must not reach p (0 * Inf is NaN, and a NaN
-                // distance would index the table out of range).  c, p and hw are wave-uniform: a
-                // scalar branch.
-                if (c - p < -hw || c - p > hw)
-                    continue;
-                float alpha = 0.f;
+            for (int u = 0; u < 4; u++) {
+                const int xx = interior ? x0 + c4 + u : border_interpolate(x0 + c4 + u, w, border);
 #pragma unroll
                 for (int ch = 0; ch < JCN; ch++)
-                    alpha = __fadd_rn(alpha, fabsf(__fsub_rn(j0[p][ch], jt[ch])));
-                alpha = __fmul_rn(alpha, scale_index);
-                const int idx = (int)alpha;
-                alpha = __fsub_rn(alpha, (float)idx);
-                const float l0 = lut_s[idx], l1 = lut_s[idx + 1];
-                const float wgt =
-                    __fmul_rn(ws[p], __fadd_rn(l0, __fmul_rn(alpha, __fsub_rn(l1, l0))));
+                    jt[u][ch] = jrow[(size_t)xx * JCN + ch];
 #pragma unroll
                 for (int ch = 0; ch < SCN; ch++)
-                    sum[p][ch] = __fadd_rn(sum[p][ch], __fmul_rn(wgt, st[ch]));
-                wsum[p] = __fadd_rn(wsum[p], wgt);
+                    st[u][ch] = srow[(size_t)xx * SCN + ch];
+                wn[u] = wrow[c4 + u + 1];
             }
-            w3 = w2;
-            w2 = w1;
-            w1 = w0;
-            w0 = wnext;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int c = c4 + u;
+                const float ws[4] = {w0, w1, w2, w3};
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    // columns of the span that lie off output p's disk are not taps of p: OpenCV
+                    // never reads them, so a NaN / Inf texel there must not reach p (0 * Inf is NaN,
+                    // and a NaN distance would index the table out of range).  c, p and hw are
+                    // wave-uniform: a scalar branch.
+                    if (c - p < -hw || c - p > hw)
+                        continue;
+                    float alpha = 0.f;
+#pragma unroll
+                    for (int ch = 0; ch < JCN; ch++)
+                        alpha = __fadd_rn(alpha, fabsf(__fsub_rn(j0[p][ch], jt[u][ch])));
+                    alpha = __fmul_rn(alpha, scale_index);
+                    const int idx = (int)alpha;
+                    alpha = __fsub_rn(alpha, (float)idx);
+                    const float l0 = lut_s[idx], l1 = lut_s[idx + 1];
+                    const float wgt =
+                        __fmul_rn(ws[p], __fadd_rn(l0, __fmul_rn(alpha, __fsub_rn(l1, l0))));
+#pragma unroll
+                    for (int ch = 0; ch < SCN; ch++)
+                        sum[p][ch] = __fadd_rn(sum[p][ch], __fmul_rn(wgt, st[u][ch]));
+                    wsum[p] = __fadd_rn(wsum[p], wgt);
+                }
+                w3 = w2;
+                w2 = w1;
+                w1 = w0;
+                w0 = wn[u];
+            }
         }
     }
     if (ty0 + ly >= h)
