@@ -1673,11 +1673,12 @@ __global__ __launch_bounds__(256) void jbf_f32_kernel(
 // disk carry weight 0 (adds +0 to the sums: the tap order per output is OpenCV's), and tiles
 // away from the image border skip borderInterpolate.  Same float operations per tap as
 // jbf_f32_kernel, so the values are identical.
-// Tile height by texel size (measured at 1080p, radius 33: 6-float texels 7.4 / 8.1 / 9.4 ms with
-// 16 / 32 / 64 rows - the texel loads thrash the vector cache with more waves per CU - 4-float
-// texels 6.3 / 5.1 / 5.9 ms, 2-float texels 4.4 / 3.9 / 3.9 ms).
+// Tile height: 32 rows for every texel size.  (8 x 1080p, radius 33, with the four-column loop:
+// 3/3-channel joint/src 328 / 449 / 459 MP/s with 16 / 32 / 64 rows, 3/1 342 / 560 / 574, 1/1 615 /
+// 618 / 621.  With one column per iteration 16 rows had been the fastest for 6-float texels: the
+// loads of more waves thrashed the vector cache without overlapping.)
 constexpr int kF32TileW = 64;
-constexpr int f32_tile_h(int jcn, int scn) { return jcn + scn >= 6 ? 16 : 32; }
+constexpr int f32_tile_h(int, int) { return 32; }
 
 template <int JCN, int SCN>
 __global__ __launch_bounds__(16 * f32_tile_h(JCN, SCN)) void jbf_f32_quad_kernel(
@@ -1723,64 +1724,82 @@ __global__ __launch_bounds__(16 * f32_tile_h(JCN, SCN)) void jbf_f32_quad_kernel
         for (int c = 0; c < SCN; c++)
             sum[p][c] = 0.f;
     }
-    for (int i = -radius; i <= radius; i++) {
-        const int hw = hwtab[i + radius];
-        const int hw4 = (hw + 3) & ~3;
-        const int yy = interior ? y + i : border_interpolate(y + i, h, border);
-        const float *jrow = joint + (img + (size_t)yy * w) * JCN;
-        const float *srow = src + (img + (size_t)yy * w) * SCN;
-        const float *wrow = sw_s + (i < 0 ? -i : i) * sw_len + (r4 + 8);  // wrow[j], zero off the disk
-        // weights of outputs 0..3 at column step c are wrow[c], wrow[c-1], wrow[c-2], wrow[c-3]
-        float w0 = wrow[-hw4], w1 = wrow[-hw4 - 1], w2 = wrow[-hw4 - 2], w3 = wrow[-hw4 - 3];
-        // four columns per iteration (the span -hw4 .. hw4+3 is a multiple of four): their texel
-        // loads are issued together, so four columns' worth of vector-cache latency overlap
-        for (int c4 = -hw4; c4 <= hw4; c4 += 4) {
-            float jt[4][JCN], st[4][SCN], wn[4];
+    // One group of four columns c4 .. c4+3 of tap row (jrow, srow, wrow): the four texels are
+    // requested together (their vector-cache latencies overlap), then consumed in tap order.
+    // EDGE: the group straddles the end of some output's disk.  Columns of the span that lie off
+    // output p's disk are not taps of p: OpenCV never reads them, so a NaN / Inf texel there must
+    // not reach p (0 * Inf is NaN, and a NaN distance would index the table out of range); c, p
+    // and hw are wave-uniform, the test is a scalar branch.  Groups inside every output's disk
+    // (all but the first and last one or two of a row) run without it.
+    auto group = [&](auto interior_c, auto edge_c, const float *jrow, const float *srow,
+                     const float *wrow, int c4, int hw, float &w0, float &w1, float &w2, float &w3)
+                     __attribute__((always_inline)) {
+        constexpr bool INTERIOR = decltype(interior_c)::value, EDGE = decltype(edge_c)::value;
+        float jt[4][JCN], st[4][SCN], wn[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int xx = interior ? x0 + c4 + u : border_interpolate(x0 + c4 + u, w, border);
+        for (int u = 0; u < 4; u++) {
+            const int xx = INTERIOR ? x0 + c4 + u : border_interpolate(x0 + c4 + u, w, border);
+#pragma unroll
+            for (int ch = 0; ch < JCN; ch++)
+                jt[u][ch] = jrow[(size_t)xx * JCN + ch];
+#pragma unroll
+            for (int ch = 0; ch < SCN; ch++)
+                st[u][ch] = srow[(size_t)xx * SCN + ch];
+            wn[u] = wrow[c4 + u + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int c = c4 + u;
+            const float ws[4] = {w0, w1, w2, w3};
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                if (EDGE && (c - p < -hw || c - p > hw))
+                    continue;
+                float alpha = 0.f;
 #pragma unroll
                 for (int ch = 0; ch < JCN; ch++)
-                    jt[u][ch] = jrow[(size_t)xx * JCN + ch];
+                    alpha = __fadd_rn(alpha, fabsf(__fsub_rn(j0[p][ch], jt[u][ch])));
+                alpha = __fmul_rn(alpha, scale_index);
+                const int idx = (int)alpha;
+                alpha = __fsub_rn(alpha, (float)idx);
+                const float l0 = lut_s[idx], l1 = lut_s[idx + 1];
+                const float wgt =
+                    __fmul_rn(ws[p], __fadd_rn(l0, __fmul_rn(alpha, __fsub_rn(l1, l0))));
 #pragma unroll
                 for (int ch = 0; ch < SCN; ch++)
-                    st[u][ch] = srow[(size_t)xx * SCN + ch];
-                wn[u] = wrow[c4 + u + 1];
+                    sum[p][ch] = __fadd_rn(sum[p][ch], __fmul_rn(wgt, st[u][ch]));
+                wsum[p] = __fadd_rn(wsum[p], wgt);
             }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int c = c4 + u;
-                const float ws[4] = {w0, w1, w2, w3};
-#pragma unroll
-                for (int p = 0; p < 4; p++) {
-                    // columns of the span that lie off output p's disk are not taps of p: OpenCV
-                    // never reads them, so a NaN / Inf texel there must not reach p (0 * Inf is NaN,
-                    // and a NaN distance would index the table out of range).  c, p and hw are
-                    // wave-uniform: a scalar branch.
-                    if (c - p < -hw || c - p > hw)
-                        continue;
-                    float alpha = 0.f;
-#pragma unroll
-                    for (int ch = 0; ch < JCN; ch++)
-                        alpha = __fadd_rn(alpha, fabsf(__fsub_rn(j0[p][ch], jt[u][ch])));
-                    alpha = __fmul_rn(alpha, scale_index);
-                    const int idx = (int)alpha;
-                    alpha = __fsub_rn(alpha, (float)idx);
-                    const float l0 = lut_s[idx], l1 = lut_s[idx + 1];
-                    const float wgt =
-                        __fmul_rn(ws[p], __fadd_rn(l0, __fmul_rn(alpha, __fsub_rn(l1, l0))));
-#pragma unroll
-                    for (int ch = 0; ch < SCN; ch++)
-                        sum[p][ch] = __fadd_rn(sum[p][ch], __fmul_rn(wgt, st[u][ch]));
-                    wsum[p] = __fadd_rn(wsum[p], wgt);
-                }
-                w3 = w2;
-                w2 = w1;
-                w1 = w0;
-                w0 = wn[u];
+            w3 = w2;
+            w2 = w1;
+            w1 = w0;
+            w0 = wn[u];
+        }
+    };
+    auto rows = [&](auto interior_c) __attribute__((always_inline)) {
+        constexpr bool INTERIOR = decltype(interior_c)::value;
+        for (int i = -radius; i <= radius; i++) {
+            const int hw = hwtab[i + radius];
+            const int hw4 = (hw + 3) & ~3;
+            const int yy = INTERIOR ? y + i : border_interpolate(y + i, h, border);
+            const float *jrow = joint + (img + (size_t)yy * w) * JCN;
+            const float *srow = src + (img + (size_t)yy * w) * SCN;
+            // wrow[j], zero off the disk; the weights of outputs 0..3 at column step c are
+            // wrow[c], wrow[c-1], wrow[c-2], wrow[c-3] and slide through registers
+            const float *wrow = sw_s + (i < 0 ? -i : i) * sw_len + (r4 + 8);
+            float w0 = wrow[-hw4], w1 = wrow[-hw4 - 1], w2 = wrow[-hw4 - 2], w3 = wrow[-hw4 - 3];
+            for (int c4 = -hw4; c4 <= hw4; c4 += 4) {
+                if (c4 - 3 >= -hw && c4 + 3 <= hw)
+                    group(interior_c, std::false_type{}, jrow, srow, wrow, c4, hw, w0, w1, w2, w3);
+                else
+                    group(interior_c, std::true_type{}, jrow, srow, wrow, c4, hw, w0, w1, w2, w3);
             }
         }
-    }
+    };
+    if (interior)
+        rows(std::true_type{});
+    else
+        rows(std::false_type{});
     if (ty0 + ly >= h)
         return;
 #pragma unroll
