@@ -1680,7 +1680,12 @@ __global__ __launch_bounds__(256) void jbf_f32_kernel(
 constexpr int kF32TileW = 64;
 constexpr int f32_tile_h(int, int) { return 32; }
 
-template <int JCN, int SCN>
+// PAIR: the colour table arrives as pairs {lut[i], lut[i+1] - lut[i]} (lut_stride floats = lut_stride/2
+// pairs per image, the last pair {0, 0}): one 8-byte LDS read per tap and output instead of two
+// 4-byte ones at random addresses, and the table ends where its values reach zero (indices past
+// the end are clamped to the last pair: weight 0 either way).  The difference is the float
+// subtraction the plain form does per tap, done once per entry.
+template <int JCN, int SCN, bool PAIR>
 __global__ __launch_bounds__(16 * f32_tile_h(JCN, SCN)) void jbf_f32_quad_kernel(
     const float *__restrict__ joint, const float *__restrict__ src, float *__restrict__ dst, int h,
     int w, int border, const float *__restrict__ luts, int lut_stride,
@@ -1690,6 +1695,7 @@ __global__ __launch_bounds__(16 * f32_tile_h(JCN, SCN)) void jbf_f32_quad_kernel
     extern __shared__ __align__(16) float f32_smem[];
     float *lut_s = f32_smem;                       // [lut_stride]
     float *sw_s = f32_smem + ((lut_stride + 3) & ~3);  // [(radius + 1) * sw_len]
+    const int last_pair = lut_stride / 2 - 1;
     constexpr int kF32TileH = f32_tile_h(JCN, SCN), kF32Threads = 16 * kF32TileH;
     const int tid = threadIdx.x;
     {
@@ -1762,9 +1768,16 @@ __global__ __launch_bounds__(16 * f32_tile_h(JCN, SCN)) void jbf_f32_quad_kernel
                 alpha = __fmul_rn(alpha, scale_index);
                 const int idx = (int)alpha;
                 alpha = __fsub_rn(alpha, (float)idx);
-                const float l0 = lut_s[idx], l1 = lut_s[idx + 1];
-                const float wgt =
-                    __fmul_rn(ws[p], __fadd_rn(l0, __fmul_rn(alpha, __fsub_rn(l1, l0))));
+                float l0, dl;
+                if (PAIR) {
+                    const float2 e = reinterpret_cast<const float2 *>(lut_s)[min(idx, last_pair)];
+                    l0 = e.x;
+                    dl = e.y;
+                } else {
+                    l0 = lut_s[idx];
+                    dl = __fsub_rn(lut_s[idx + 1], l0);
+                }
+                const float wgt = __fmul_rn(ws[p], __fadd_rn(l0, __fmul_rn(alpha, dl)));
 #pragma unroll
                 for (int ch = 0; ch < SCN; ch++)
                     sum[p][ch] = __fadd_rn(sum[p][ch], __fmul_rn(wgt, st[u][ch]));
@@ -1969,7 +1982,8 @@ extern "C" size_t rf_jbf_f32_workspace_bytes(int n, int joint_cn)
 {
     if (n <= 0 || (joint_cn != 1 && joint_cn != 3))
         return 0;
-    const size_t lut = (size_t)(rf::kF32BinsPerChannel * joint_cn + 2) * sizeof(float);
+    // room for the pair form of the table (jbf_f32_quad_kernel): two floats per entry
+    const size_t lut = (size_t)(rf::kF32BinsPerChannel * joint_cn + 3) * 2 * sizeof(float);
     return (size_t)n * (lut + 2 * sizeof(uint32_t) + sizeof(float)) + 256;
 }
 
@@ -2060,16 +2074,57 @@ extern "C" int rf_jbf_f32(const float *joint, const float *src, float *dst, int 
         }
     }
     RF_HIP_CHECK(hipMemcpy(d_scale, scales.data(), scales.size() * 4, hipMemcpyHostToDevice));
-    RF_HIP_CHECK(hipMemcpy(d_luts, luts.data(), luts.size() * 4, hipMemcpyHostToDevice));
     // register-tiled kernel when its LDS tables fit (always at the reference's radius); the
     // one-thread-per-pixel kernel otherwise, and as the cross-check (debug option jbf_f32_untiled)
-    const size_t quad_lds = (size_t)(((bins + 2 + 3) & ~3) + (radius + 1) * t.sw_len) * sizeof(float);
+    size_t quad_lds = (size_t)(((bins + 2 + 3) & ~3) + (radius + 1) * t.sw_len) * sizeof(float);
     const bool quad = quad_lds <= 64 * 1024 && !debug_get(kDbgJbfF32Untiled);
+    // Pair form of the table (see jbf_f32_quad_kernel) when it fits LDS beside the weight rows: a
+    // table that reaches zero ends there; z = first zero entry (every entry after it is zero by
+    // construction)
+    int lut_stride = bins + 2;
+    bool pair = false;
+    if (quad) {
+        int zmax = 0;
+        for (int i = 0; i < n; i++) {
+            const float *lut = luts.data() + (size_t)i * (bins + 2);
+            int z = 0;
+            while (z < bins + 2 && lut[z] > 0.f)
+                z++;
+            zmax = std::max(zmax, z);
+        }
+        const int npair = zmax + 1;  // pairs 0 .. zmax; pair zmax = {0, 0}
+        const size_t pair_lds =
+            (size_t)(((2 * npair + 3) & ~3) + (radius + 1) * t.sw_len) * sizeof(float);
+        if (npair <= bins + 3 && pair_lds <= 64 * 1024) {
+            pair = true;
+            lut_stride = 2 * npair;
+            std::vector<float> pairs((size_t)n * lut_stride);
+            for (int i = 0; i < n; i++) {
+                const float *lut = luts.data() + (size_t)i * (bins + 2);
+                float *pp = pairs.data() + (size_t)i * lut_stride;
+                for (int b = 0; b < npair; b++) {
+                    const float l0 = b < bins + 2 ? lut[b] : 0.f;
+                    const float l1 = b + 1 < bins + 2 ? lut[b + 1] : 0.f;
+                    pp[2 * b] = l0;
+                    pp[2 * b + 1] = l1 - l0;
+                }
+            }
+            luts.swap(pairs);
+            quad_lds = (size_t)(((lut_stride + 3) & ~3) + (radius + 1) * t.sw_len) * sizeof(float);
+        }
+    }
+    RF_HIP_CHECK(hipMemcpy(d_luts, luts.data(), luts.size() * 4, hipMemcpyHostToDevice));
     dim3 grid(ceil_div(w, 64), ceil_div(h, 4), n);
 #define RF_F32(J_, S_)                                                                         \
     do {                                                                                       \
-        if (quad)                                                                              \
-            hipLaunchKernelGGL((jbf_f32_quad_kernel<J_, S_>),                                  \
+        if (quad && pair)                                                                      \
+            hipLaunchKernelGGL((jbf_f32_quad_kernel<J_, S_, true>),                            \
+                               dim3(ceil_div(w, kF32TileW), ceil_div(h, f32_tile_h(J_, S_)), n), \
+                               dim3(16 * f32_tile_h(J_, S_)), quad_lds, stream, joint, src, dst, \
+                               h, w, border, d_luts, lut_stride, d_scale, t.d_swsym, t.sw_len, \
+                               t.r4, radius, t.d_hw);                                          \
+        else if (quad)                                                                         \
+            hipLaunchKernelGGL((jbf_f32_quad_kernel<J_, S_, false>),                           \
                                dim3(ceil_div(w, kF32TileW), ceil_div(h, f32_tile_h(J_, S_)), n), \
                                dim3(16 * f32_tile_h(J_, S_)), quad_lds, stream, joint, src, dst, \
                                h, w, border, d_luts, bins + 2, d_scale, t.d_swsym, t.sw_len,   \
