@@ -961,8 +961,12 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
         // 4K - the 2r warm-up rows of a segment are cheap - and slower above; a model that picks
         // the segment count by whole rounds of resident workgroups was no better.)
         // (m_fill: the images in flight on the device, i.e. both halves of a chunk)
+        // ... and no longer than about three windows (C5 shard, 57 images per half: 1080-row
+        // segments, the 684 workgroups a half then has, 14.0-14.2 GP/s; 540 rows 14.1-14.3; 270 rows
+        // 14.5; 180 rows 14.5; 135 rows 14.5; 68 rows 14.0 - measured in one process each)
+        const int seg_cap = std::max(3 * (2 * radius + 1), 256);
         int seg_rows = h;
-        while ((long long)strips * ceil_div(h, seg_rows) * m_fill < 1024 &&
+        while (((long long)strips * ceil_div(h, seg_rows) * m_fill < 1024 || seg_rows > seg_cap) &&
                seg_rows > 2 * (2 * radius + 1) && seg_rows > 32)
             seg_rows = (seg_rows + 1) / 2;
         if (debug_get(kDbgGfSegRows) > 0)
