@@ -931,7 +931,6 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
     // stage-1 strips: stage1_threads x stage1_cols columns, 2r of them halo
     const int strips3 = ceil_div(w, stage1_threads(3) * stage1_cols(3) - 2 * radius);
     const int strips1 = ceil_div(w, stage1_threads(1) * stage1_cols(1) - 2 * radius);
-    const int strips = src_cn == 3 ? strips3 : strips1;
 
     // 3-channel sources: find the images whose channels are identical (see the file header)
     int *colour_all = nullptr;
@@ -961,30 +960,39 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
         // 4K - the 2r warm-up rows of a segment are cheap - and slower above; a model that picks
         // the segment count by whole rounds of resident workgroups was no better.)
         // (m_fill: the images in flight on the device, i.e. both halves of a chunk)
-        // ... and no longer than about three windows (C5 shard, 57 images per half: 1080-row
-        // segments, the 684 workgroups a half then has, 14.0-14.2 GP/s; 540 rows 14.1-14.3; 270 rows
-        // 14.5; 180 rows 14.5; 135 rows 14.5; 68 rows 14.0 - measured in one process each)
-        const int seg_cap = std::max(3 * (2 * radius + 1), 256);
-        int seg_rows = h;
-        while (((long long)strips * ceil_div(h, seg_rows) * m_fill < 1024 || seg_rows > seg_cap) &&
-               seg_rows > 2 * (2 * radius + 1) && seg_rows > 32)
-            seg_rows = (seg_rows + 1) / 2;
-        if (debug_get(kDbgGfSegRows) > 0)
-            seg_rows = std::min(h, debug_get(kDbgGfSegRows));
-        const int segs = ceil_div(h, seg_rows);
+        // How many workgroups that is depends on the instantiation (each figure measured against
+        // its alternatives in one process).  1-channel kernels: the C5 shard (3 passes; chunks of 37
+        // images, 18 + 19 per half) 14.1 / 14.5 / 14.1-14.3 / 14.0-14.2 GP/s at 135 / 270 / 540 / 1080
+        // rows, i.e. 3,552 / 1,776 / 888 / 444 workgroups in flight; a single pass over 32 images
+        // prefers 135 rows by 4 % (6.20 / 6.45 / 6.56 ms at 135 / 270 / 540) - the chained passes are
+        // what the filter is used for.  The 3-channel kernel (21 running sums: its warm-up rows
+        // cost more) wants fewer and longer segments, but not whole images: 32 images 15.7 / 16.4 /
+        // 17.0 ms at 540 / 270 / 135 rows (1,280 / 2,560 / 5,120 workgroups), 96 images 48.2 / 48.9 /
+        // 50.7 ms at 540 / 270 / 1080 rows.
+        auto pick_seg = [&](int strips_k, long long min_wgs, int cap) {
+            int seg = h;
+            while (((long long)strips_k * ceil_div(h, seg) * m_fill < min_wgs || seg > cap) &&
+                   seg > 2 * (2 * radius + 1) && seg > 32)
+                seg = (seg + 1) / 2;
+            if (debug_get(kDbgGfSegRows) > 0)
+                seg = std::min(h, debug_get(kDbgGfSegRows));
+            return seg;
+        };
+        const int seg_rows1 = pick_seg(strips1, 1536, h);
+        const int seg_rows3 = pick_seg(strips3, 1024, std::max(6 * (2 * radius + 1), 512));
         for (int it = 0; it < iterations; it++) {
             const uint8_t *s0 = (it == 0 ? src : (const uint8_t *)dst) + (size_t)i0 * npx * src_cn;
-            const dim3 ga3(strips3, segs, m), ga1(strips1, segs, m);
+            const dim3 ga3(strips3, ceil_div(h, seg_rows3), m), ga1(strips1, ceil_div(h, seg_rows1), m);
 #define RF_GF_STAGE1(MODE)                                                                         \
     do {                                                                                           \
         if (src_cn == 3) {                                                                         \
             hipLaunchKernelGGL((gf_stage1_kernel<3, 3, MODE>), ga3, dim3(stage1_threads(3)), 0, st, \
-                               g0, s0, ab, h, w, radius, eps_f, eps_small, seg_rows, colour, gs);  \
+                               g0, s0, ab, h, w, radius, eps_f, eps_small, seg_rows3, colour, gs); \
             hipLaunchKernelGGL((gf_stage1_kernel<1, 3, MODE>), ga1, dim3(stage1_threads(1)), 0, st, \
-                               g0, s0, ab, h, w, radius, eps_f, eps_small, seg_rows, colour, gs);  \
+                               g0, s0, ab, h, w, radius, eps_f, eps_small, seg_rows1, colour, gs); \
         } else {                                                                                   \
             hipLaunchKernelGGL((gf_stage1_kernel<1, 1, MODE>), ga1, dim3(stage1_threads(1)), 0, st, \
-                               g0, s0, ab, h, w, radius, eps_f, eps_small, seg_rows, colour, gs);  \
+                               g0, s0, ab, h, w, radius, eps_f, eps_small, seg_rows1, colour, gs); \
         }                                                                                          \
     } while (0)
             if (!keep_gs)
