@@ -596,9 +596,9 @@ def run_rank(args):
         del wl.joint, wl.src, wl.dst
         torch.cuda.empty_cache()
         # C5 runs at its stated shard (128 x 4K per GPU: 10 GB of images + a workspace of up to
-        # 16 GiB) when the device has the room, else at batch 16
+        # 32 GiB) when the device has the room, else at batch 16
         free_b, _ = torch.cuda.mem_get_info()
-        c5_batch = CONFIGS["c5"][1] if free_b >= (48 << 30) else 16
+        c5_batch = CONFIGS["c5"][1] if free_b >= (64 << 30) else 16
         for key, cfg, nb in (("c3_chain", "c3", 256), ("c5_gf", "c5", c5_batch)):
             k2, _, h2, w2 = CONFIGS[cfg]
             w2l = Workload(k2, nb, h2, w2, args, torch, rf, device, seed=1234 + 1000 * int(cfg[1]))

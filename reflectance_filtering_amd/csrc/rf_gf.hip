@@ -835,7 +835,7 @@ size_t gf_workspace_cap()
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            c = std::min(std::max(c, (size_t)prop.totalGlobalMem / 16), (size_t)16 << 30);
+            c = std::min(std::max(c, (size_t)prop.totalGlobalMem / 8), (size_t)32 << 30);
         else
             (void)hipGetLastError();  // no device: not an error of this call
         cap = c;
@@ -856,8 +856,9 @@ extern "C" size_t rf_gf_workspace_bytes(int n, int h, int w, int guide_cn, int s
         return 0;
     const size_t per_img = (size_t)h * w * (4 * src_cn) * (sizeof(float) + sizeof(double));
     // enough images in flight to fill the chip and to make the tails of the launches small: capped
-    // at 1/16 of the device's memory, at most 16 GiB (6 GiB when no device can be asked).  C5 shard
-    // (128 x 4K, 3 passes, round 2): 91.5 ms with 6 GiB (13 images per chunk), 86.6 ms with 16 GiB (36).
+    // at 1/8 of the device's memory, at most 32 GiB (6 GiB when no device can be asked).  C5 shard
+    // (128 x 4K, 3 passes): round 2 91.5 ms with 6 GiB (13 images per chunk), 86.6 ms with 16 GiB (37);
+    // round 3 70.7 / 68.6 / 70.1 ms with 16 / 32 / 64 GiB (chunks of 37 / 74 / all 128 images).
     size_t imgs = (size_t)n;
     const size_t cap = rf::gf_workspace_cap();
     if (imgs * per_img > cap)

@@ -9,7 +9,7 @@ from . import _ffi
 
 _gf_workspaces = {}
 _GF_CACHE_PER_DEVICE = 4
-_GF_CACHE_BYTES_PER_DEVICE = 32 << 30     # ... and at most this much scratch kept per device
+_GF_CACHE_BYTES_PER_DEVICE = 64 << 30     # ... and at most this much scratch kept per device
 _cnn_consts = {}
 
 
@@ -52,8 +52,8 @@ def joint_bilateral_u8(joint, src, d, sigma_color, sigma_space, border=_ffi.BORD
 def gf_workspace(n, h, w, scn, radius, device, torch):
     """Guided-filter scratch for the CURRENT stream of `device`, cached per (device, stream):
     two streams (or threads with their own streams) never share planes.  The cache keeps one
-    buffer per key, sized by rf_gf_workspace_bytes (capped at 1/16 of the device's memory, at most
-    16 GiB), at most four buffers and 32 GiB per device; release_workspaces() drops them."""
+    buffer per key, sized by rf_gf_workspace_bytes (capped at 1/8 of the device's memory, at most
+    32 GiB), at most four buffers and 64 GiB per device; release_workspaces() drops them."""
     lib = _ffi.load_library()
     need = lib.rf_gf_workspace_bytes(n, h, w, 3, scn, radius)
     dev = device.index if device.index is not None else torch.cuda.current_device()
