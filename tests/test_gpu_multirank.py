@@ -129,3 +129,22 @@ print("ok", n)
         o, e = p.communicate(timeout=600)
         assert p.returncode == 0, e.decode()[-3000:]
         assert "ok %d" % world in o.decode().splitlines()      # RCCL prints its banner to stdout too
+
+
+def test_bench_measures_its_traffic_live(gpu):
+    """`bench.py --traffic live`: the two rocprofv3 --pmc child passes run, the kernel is found in
+    their counter files and `roofline.traffic` is of the order of the algorithmic bytes (a small
+    batch: the halo share is larger than at 256 images)."""
+    import shutil
+    if not (shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3")):
+        pytest.skip("no rocprofv3 on this machine")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "8", "--steps", "1", "--warmup",
+           "1", "--cpu-seconds", "0", "--no-extras", "--traffic", "live"]
+    p = subprocess.run(cmd, env=_clean_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    out = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][0])
+    roof = out["roofline"]
+    assert roof["traffic_source"].startswith("measured by this run"), (roof, p.stderr.decode()[-2000:])
+    assert "jbf" in roof["kernel"]
+    assert 0.8 < roof["traffic"] / roof["algorithmic_bytes_per_launch"] < 2.0
