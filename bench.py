@@ -641,7 +641,10 @@ def run_rank(args):
         if kind == "jbf" and mode != "off":
             if mode == "live" or (mode == "auto" and world == 1 and not being_profiled()
                                   and os.environ.get("RF_BENCH_CHILD") != "1"):
-                traffic, source = live_traffic(args, n, h, w)
+                try:
+                    traffic, source = live_traffic(args, n, h, w)
+                except Exception as exc:              # noqa: BLE001 - a measurement aid, never fatal
+                    traffic, source = None, repr(exc)
                 if traffic is None:
                     sys.stderr.write("bench.py: live traffic measurement unavailable: %s\n" % source)
             if traffic is None:
