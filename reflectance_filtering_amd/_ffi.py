@@ -10,7 +10,9 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librf_hip.so")
+# RF_LIB_PATH: development aid for A/B timing of two builds of the library on one box
+# (tools/gf_c5_exp.py in two processes); it still has to be a librf_hip.so, nothing else loads.
+LIB_PATH = os.environ.get("RF_LIB_PATH") or os.path.join(_HERE, "librf_hip.so")
 
 RF_OK, RF_E_BADARG, RF_E_UNSUPPORTED, RF_E_WORKSPACE, RF_E_HIP = 0, -1, -2, -3, -4
 BORDER_CONSTANT, BORDER_REPLICATE, BORDER_REFLECT, BORDER_WRAP, BORDER_REFLECT_101 = range(5)
@@ -29,6 +31,8 @@ EXPORTS = ("rf_version", "rf_last_error", "rf_shutdown", "rf_jbf_u8", "rf_gf_wor
 
 # include/reflectance_filtering_debug.h: test / benchmark switches, not part of the boundary
 DEBUG_EXPORTS = ("rf_debug_option", "rf_debug_clock_probe")
+# switches that leave work out (wrong results, timing experiments only); all others keep the bytes
+RESULT_CHANGING_OPTIONS = ("jbf_stage_only", "gf_exp_skip")
 
 _lib = None
 _lock = threading.Lock()
@@ -92,11 +96,25 @@ def load_library():
         lib.rf_debug_clock_probe.argtypes = [vp, ci, vp]
         lib.rf_debug_clock_probe.restype = ci
         # RF_DEBUG_OPTIONS="name=value,...": preset the test / benchmark switches of
-        # include/reflectance_filtering_debug.h for a whole process (timing experiments only)
+        # include/reflectance_filtering_debug.h for a whole process (timing experiments only).
+        # Every preset is announced on stderr - loudly for the switches that change results.
+        import sys
         for item in filter(None, os.environ.get("RF_DEBUG_OPTIONS", "").split(",")):
             name, _, value = item.partition("=")
-            if lib.rf_debug_option(name.strip().encode(), int(value or 1)) < 0:
+            name = name.strip()
+            try:
+                number = int(value or 1)
+            except ValueError:
+                raise RFError("RF_DEBUG_OPTIONS: %r is not an integer (option %r)" % (value, name))
+            if lib.rf_debug_option(name.encode(), number) < 0:
                 raise RFError("RF_DEBUG_OPTIONS: unknown debug option %r" % name)
+            if name in RESULT_CHANGING_OPTIONS and number:
+                sys.stderr.write("reflectance_filtering_amd: WARNING: RF_DEBUG_OPTIONS sets %s=%d, a "
+                                 "TIMING-ONLY switch - results of this process are WRONG\n"
+                                 % (name, number))
+            else:
+                sys.stderr.write("reflectance_filtering_amd: RF_DEBUG_OPTIONS sets %s=%d\n"
+                                 % (name, number))
         _lib = lib
         return lib
 

@@ -71,7 +71,7 @@ inline bool ranges_overlap(const void *a, size_t na, const void *b, size_t nb)
 
 // Test / benchmark switches behind rf_debug_option() (include/reflectance_filtering_debug.h).
 // All zero unless a test or tool sets them; none of them changes the bytes of a result except
-// kDbgJbfStageOnly, which leaves dst unwritten.
+// kDbgJbfStageOnly, which leaves dst unwritten, and kDbgGfExpSkip, which leaves kernels out.
 enum DebugOption {
     kDbgGfTwoKernel = 0,   // guided filter: row-sum / column-sum kernel pair instead of the fused stage 2
     kDbgJbfStageOnly,      // joint bilateral: stage the tile and return (timing only)
@@ -84,6 +84,7 @@ enum DebugOption {
     kDbgGfOneStream,       // guided filter: the whole chunk on the caller's stream (no side stream)
     kDbgGfForceTwoStreams, // guided filter: fork the side stream for any chunk of two or more images
     kDbgGfGuideCache,      // guided filter: keep the guide statistics of the first pass of an iterated call (experiment)
+    kDbgGfExpSkip,         // guided filter, TIMING ONLY (wrong results): bit 0 no stage 1, bit 1 no row states, bit 2 no column walk
     kDbgCount
 };
 int debug_get(int id);

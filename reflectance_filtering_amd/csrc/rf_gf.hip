@@ -95,7 +95,15 @@ __device__ inline uint32_t wave_inclusive_scan(uint32_t v)
     return v;
 }
 
-__device__ inline float mean_of(uint32_t s, double scale) { return (float)((double)s * scale); }
+// mean = (float)((double)S * scale), OpenCV's `(float)(sum * scale)` on the exact window sum S.
+// (double)S is formed without a conversion instruction: 2^52 + S has the bit pattern
+// {0x43300000, S}, and fma(2^52 + S, scale, -(2^52 * scale)) rounds the exact product S * scale
+// once (2^52 * scale is a power-of-two multiple of scale, hence exact) - the same double as
+// cvt + mul, one 4-cycle instruction less per quantity and pixel.  nbias = -(2^52 * scale).
+__device__ inline float mean_of(uint32_t s, double scale, double nbias)
+{
+    return (float)__fma_rn(__hiloint2double(0x43300000, (int)s), scale, nbias);
+}
 
 // index into the 6-entry symmetric store: (0,0)=0 (0,1)=1 (0,2)=2 (1,1)=3 (1,2)=4 (2,2)=5
 __device__ constexpr int sym(int i, int j)
@@ -124,16 +132,22 @@ constexpr int kGsFloats = kGsFloatsPublic;
 // it is what gives a zero numerator its sign.  Anything else takes the plain divisions.
 __device__ inline void div6_by(const float *num, float den, float *out)
 {
-    const uint32_t ud = __float_as_uint(den) & 0x7fffffffu;
-    uint32_t lo = 0xffffffffu, hi = 0u;
+    // |den| in [2^-30, 2^50]; every numerator zero or in [2^-40, 2^36].  The upper bound is tested on
+    // the SUM of the magnitudes (source modifiers, no masking instructions; a NaN or an infinity
+    // anywhere propagates and fails the comparison; a sum above 2^36 whose terms are all below it
+    // merely takes the plain divisions); the smallest non-zero numerator is an unsigned minimum
+    // over (bits << 1) - 2, which drops the sign and sends a zero to the top (one v_lshl_add_u32
+    // per numerator).
+    const float ad = fabsf(den);
+    const float hi = ((fabsf(num[0]) + fabsf(num[1])) + (fabsf(num[2]) + fabsf(num[3]))) +
+                     (fabsf(num[4]) + fabsf(num[5]));
+    uint32_t lo = 0xffffffffu;
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
-        const uint32_t u = __float_as_uint(num[i]) & 0x7fffffffu;
-        lo = min(lo, u - 1u);  // zero wraps to the top: zero numerators are fine
-        hi = max(hi, u);
-    }
-    const bool fast = ud >= 0x30800000u && ud <= 0x58800000u &&  // 2^-30 .. 2^50
-                      lo >= 0x2b800000u - 1u && hi <= 0x51800000u;  // 2^-40 .. 2^36
+    for (int i = 0; i < 6; i++)
+        lo = min(lo, (__float_as_uint(num[i]) << 1) - 2u);
+    // (comparisons written so that a NaN anywhere fails them)
+    const bool fast = ad >= 0x1p-30f && ad <= 0x1p50f && hi <= 0x1p36f &&
+                      lo >= (0x2b800000u << 1) - 2u;  // 2^-40
     if (fast) {
         const float r0 = __builtin_amdgcn_rcpf(den);
         const float e = __fmaf_rn(-den, r0, 1.0f);
@@ -288,6 +302,7 @@ __global__ __launch_bounds__(stage1_threads(SCN)) void gf_stage1_kernel(
     float *gsimg = MODE == kS1Full ? nullptr : gs + (size_t)blockIdx.z * npx * kGsFloats;
     const int ks = 2 * radius + 1;
     const double scale = 1.0 / (double)(ks * ks);
+    const double nbias = -(4503599627370496.0 * scale);
 
     int gx[kACols];
 #pragma unroll
@@ -438,7 +453,7 @@ __global__ __launch_bounds__(stage1_threads(SCN)) void gf_stage1_kernel(
             float m[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; q++)
-                m[q] = mean_of(pfx[q][c + radius + 1] - pfx[q][c - radius], scale);
+                m[q] = mean_of(pfx[q][c + radius + 1] - pfx[q][c - radius], scale, nbias);
             const size_t pix = (size_t)y * w + x;
             float ab_px[4 * SCN];
             if (MODE == kS1Reuse) {
@@ -996,7 +1011,9 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
                                g0, s0, ab, h, w, radius, eps_f, eps_small, seg_rows1, colour, gs); \
         }                                                                                          \
     } while (0)
-            if (!keep_gs)
+            if (debug_get(kDbgGfExpSkip) & 1)
+                ;  // timing experiment: no stage 1 (results wrong)
+            else if (!keep_gs)
                 RF_GF_STAGE1(kS1Full);
             else if (it == 0)
                 RF_GF_STAGE1(kS1Keep);
@@ -1005,7 +1022,8 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
 #undef RF_GF_STAGE1
             const int row_blocks = ceil_div(h, kBRows);
             if (fused) {
-                const GfFusedArgs fa = {ab, rows, g0, d0, m, h, w, nb, src_cn, colour, st};
+                const GfFusedArgs fa = {ab, rows, g0, d0, m, h, w, nb, src_cn, colour, st,
+                                        debug_get(kDbgGfExpSkip)};
                 fused_launch(fa);
                 continue;
             }

@@ -632,6 +632,7 @@ struct GfFusedArgs {
     int m, h, w, nb, src_cn;
     const int *colour;
     hipStream_t stream;
+    int exp_skip;  // timing experiments only (debug option "gf_exp_skip"): bit 1 no row states, bit 2 no column walk
 };
 typedef void (*GfFusedLaunch)(const GfFusedArgs &);
 GfFusedLaunch gf_fused_launcher(int radius);  // nullptr outside 1 .. kGfFusedMaxRadius
@@ -641,11 +642,13 @@ void gf_fused_launch(const GfFusedArgs &a)
 {
     const int row_blocks = (a.h + kBRows - 1) / kBRows;
     const int np = 4 * a.src_cn;
-    hipLaunchKernelGGL((gf_rowstate_kernel<R>), dim3((unsigned)(a.m * a.src_cn * row_blocks)),
-                       dim3(256), 0, a.stream, a.ab, a.states, a.h, a.w, row_blocks, np, a.colour,
-                       np, a.nb);
+    if (!(a.exp_skip & 2))
+        hipLaunchKernelGGL((gf_rowstate_kernel<R>), dim3((unsigned)(a.m * a.src_cn * row_blocks)),
+                           dim3(256), 0, a.stream, a.ab, a.states, a.h, a.w, row_blocks, np, a.colour,
+                           np, a.nb);
     const int pairs = a.m * a.nb;
-    hipLaunchKernelGGL((gf_colwalk_kernel<R>), dim3(8u * (unsigned)((pairs + 7) / 8) * a.src_cn),
+    if (!(a.exp_skip & 4))
+        hipLaunchKernelGGL((gf_colwalk_kernel<R>), dim3(8u * (unsigned)((pairs + 7) / 8) * a.src_cn),
                        dim3(128), 0, a.stream, a.ab, a.states, a.guide, a.dst, a.h, a.w, a.nb, pairs,
                        a.src_cn, a.colour);
 }

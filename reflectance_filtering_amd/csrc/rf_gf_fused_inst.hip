@@ -16,6 +16,9 @@ GfFusedLaunch find(int radius)
     if constexpr (R > kGfFusedMaxRadius) {
         return nullptr;
     } else {
+#ifdef RF_GF_DEV_ONLY  // development builds: only this radius is instantiated (make GF_DEV_ONLY=45)
+        if constexpr (R == RF_GF_DEV_ONLY)
+#endif
         if (radius == R)
             return &gf_fused_launch<R>;
         return find<R + RF_GF_PARTS>(radius);

@@ -35,6 +35,24 @@ __global__ void read16_kernel(const uint4 *p, size_t n16, uint32_t *sink)
         sink[0] = acc;
 }
 
+// Round 4: the guided-filter kernels load 1, 4 and 8 bytes per lane (guide / src bytes, float
+// row states, double sums); the same "read N bytes once" with those widths.
+template <typename T>
+__global__ void readT_kernel(const T *p, size_t n, uint32_t *sink)
+{
+    uint32_t acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const T v = p[i];
+        uint32_t w[(sizeof(T) + 3) / 4] = {0};
+        __builtin_memcpy(w, &v, sizeof(T));
+        for (unsigned k = 0; k < (sizeof(T) + 3) / 4; ++k)
+            acc ^= w[k];
+    }
+    if (acc == 0x7bu)
+        sink[0] = acc;
+}
+
 int main()
 {
     const size_t bytes = (size_t)3 << 30;  // 3 GiB >> 256 MiB Infinity Cache
@@ -47,7 +65,14 @@ int main()
     hipLaunchKernelGGL(read12_kernel, dim3(4096), dim3(256), 0, 0, buf, bytes / 12, sink);
     hipLaunchKernelGGL(read16_kernel, dim3(4096), dim3(256), 0, 0, (const uint4 *)buf, bytes / 16,
                        sink);
+    // 1 B/lane reads 1 GiB (a third of the buffer: 1-byte loads are slow), 4 and 8 B/lane all of it
+    hipLaunchKernelGGL(readT_kernel<uint8_t>, dim3(8192), dim3(256), 0, 0, buf, bytes / 3, sink);
+    hipLaunchKernelGGL(readT_kernel<uint32_t>, dim3(4096), dim3(256), 0, 0, (const uint32_t *)buf,
+                       bytes / 4, sink);
+    hipLaunchKernelGGL(readT_kernel<uint2>, dim3(4096), dim3(256), 0, 0, (const uint2 *)buf,
+                       bytes / 8, sink);
     hipDeviceSynchronize();
-    printf("each kernel read %zu bytes once\n", bytes);
+    printf("readT_kernel<uint8_t> read %zu bytes once\n", bytes / 3);
+    printf("each other kernel read %zu bytes once\n", bytes);
     return 0;
 }
