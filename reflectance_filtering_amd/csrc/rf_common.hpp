@@ -84,6 +84,8 @@ enum DebugOption {
     kDbgGfOneStream,       // guided filter: the whole chunk on the caller's stream (no side stream)
     kDbgGfForceTwoStreams, // guided filter: fork the side stream for any chunk of two or more images
     kDbgGfGuideCache,      // guided filter: keep the guide statistics of the first pass of an iterated call (experiment)
+    kDbgGfChained,         // guided filter: chained column walk (no row-walk kernel; measured slower, profiles/r04_gf_chained.md)
+    kDbgGfNoCompact,       // guided filter: iterated calls hand grey images on as three channels in dst (not one byte per pixel)
     kDbgGfExpSkip,         // guided filter, TIMING ONLY (wrong results): bit 0 no stage 1, bit 1 no row states, bit 2 no column walk
     kDbgCount
 };

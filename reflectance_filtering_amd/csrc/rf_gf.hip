@@ -277,8 +277,10 @@ template <int SCN, int SPX, int MODE>
 __global__ __launch_bounds__(stage1_threads(SCN)) void gf_stage1_kernel(
     const uint8_t *__restrict__ guide, const uint8_t *__restrict__ src, float *__restrict__ ab,
     int h, int w, int radius, float eps_f, int eps_small, int seg_rows,
-    const int *__restrict__ colour, float *__restrict__ gs)
+    const int *__restrict__ colour, float *__restrict__ gs, int ab_groups)
 {
+    // ab_groups: plane groups (src channels) an image has in ab - SPX, or 3 when a grey 3-channel
+    // image is read from its one-byte-per-pixel intermediate (SPX = 1, see rf_gf_u8)
     if (wrong_variant<SCN>(colour, blockIdx.z))
         return;
     using Q = Quant<SCN, MODE != kS1Reuse>;
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(stage1_threads(SCN)) void gf_stage1_kernel(
     const size_t npx = (size_t)h * w;
     const uint8_t *gimg = guide + (size_t)blockIdx.z * npx * 3;
     const uint8_t *simg = src + (size_t)blockIdx.z * npx * SPX;
-    float *abimg = ab + (size_t)blockIdx.z * npx * (SPX * 4);
+    float *abimg = ab + (size_t)blockIdx.z * npx * (ab_groups * 4);
     float *gsimg = MODE == kS1Full ? nullptr : gs + (size_t)blockIdx.z * npx * kGsFloats;
     const int ks = 2 * radius + 1;
     const double scale = 1.0 / (double)(ks * ks);
@@ -863,13 +865,39 @@ size_t gf_header_bytes(int n) { return (((size_t)n * sizeof(int)) + 255) & ~(siz
 
 }  // namespace rf
 
+namespace rf {
+// Scratch per image in flight, by stage-2 form (np = 4 x src channels float planes alpha/beta):
+//   two-kernel   alpha/beta + a double row sum per pixel and plane
+//   row walk     alpha/beta + a double state per 16 pixels and plane
+//   chained      alpha/beta + the hand-off words (16 B per lane, 64 lanes per sub-tile and block)
+//                + the head sums (a double per row and plane) + the part's sync words
+size_t gf_per_img_two_kernel(size_t npx, int np) { return npx * np * (sizeof(float) + sizeof(double)); }
+size_t gf_per_img_row_walk(size_t npx, int np, int nb, int h)
+{
+    return (size_t)np * (npx * sizeof(float) + (size_t)nb * h * sizeof(double));
+}
+constexpr size_t kGfSyncBytes = 256;
+size_t gf_chain_xst_bytes(int src_cn, int nb, int h, int radius)
+{
+    return (size_t)src_cn * nb * gf_chain_nsub(h, radius) * 64 * 16;
+}
+size_t gf_per_img_chained(size_t npx, int np, int nb, int h, int radius)
+{
+    return kGfSyncBytes + gf_chain_xst_bytes(np / 4, nb, h, radius) + (size_t)np * h * sizeof(double) +
+           npx * np * sizeof(float);
+}
+}  // namespace rf
+
 extern "C" size_t rf_gf_workspace_bytes(int n, int h, int w, int guide_cn, int src_cn, int radius)
 {
     (void)guide_cn;
-    (void)radius;
     if (n <= 0 || h <= 0 || w <= 0 || (src_cn != 1 && src_cn != 3))
         return 0;
-    const size_t per_img = (size_t)h * w * (4 * src_cn) * (sizeof(float) + sizeof(double));
+    // the larger of the forms a call may take (small images: the chained form's fixed part)
+    size_t per_img = rf::gf_per_img_two_kernel((size_t)h * w, 4 * src_cn);
+    if (radius >= 1 && radius <= rf::kGfFusedMaxRadius)
+        per_img = std::max(per_img, rf::gf_per_img_chained((size_t)h * w, 4 * src_cn,
+                                                           rf::ceil_div(w, rf::kSB), h, radius));
     // enough images in flight to fill the chip and to make the tails of the launches small: capped
     // at 1/8 of the device's memory, at most 32 GiB (6 GiB when no device can be asked).  C5 shard
     // (128 x 4K, 3 passes): round 2 91.5 ms with 6 GiB (13 images per chunk), 86.6 ms with 16 GiB (37);
@@ -913,20 +941,29 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
         return RF_OK;
     const int np = 4 * src_cn;
     const size_t npx = (size_t)h * w;
-    const size_t per_img = npx * np * (sizeof(float) + sizeof(double));
+    const int nb = ceil_div(w, kSB);
     const size_t header = gf_header_bytes(n);
-    if (workspace_bytes < header + per_img)
-        return fail(RF_E_WORKSPACE, "rf_gf_u8: workspace %zu B < %zu B needed for one image",
-                    workspace_bytes, header + per_img);
     hipStream_t stream = (hipStream_t)stream_;
-    // fused stage 2 (row states + column walk) for the instantiated radii; the debug option
-    // "gf_two_kernel" forces the row-sum / column-sum kernel pair (cross-check of tests and tools)
+    // Stage 2 (box means of alpha/beta), three forms with identical bytes:
+    //   row walk + column walk (default for the instantiated radii 1..96)
+    //   chained column walk (debug option "gf_chained": no row-walk kernel, every block takes its row
+    //       sums from its left neighbour; identical bytes, measured SLOWER - the stagger between
+    //       neighbouring blocks costs the L2 sharing of their operand lines, profiles/r04_gf_chained.md)
+    //   row-sum / column-sum kernel pair (radius 0 and 97..120; debug option "gf_two_kernel")
     // (the fused kernels index planes with 32-bit element offsets: images below 2^28 pixels)
     const GfFusedLaunch fused_launch = gf_fused_launcher(radius);
-    const bool fused = !debug_get(kDbgGfTwoKernel) && fused_launch != nullptr &&
-                       npx < ((size_t)1 << 28);
-    const int nb = ceil_div(w, kSB);
-    const size_t per_img_fused = (size_t)np * (npx * sizeof(float) + (size_t)nb * h * sizeof(double));
+    const bool can_fuse = !debug_get(kDbgGfTwoKernel) && fused_launch != nullptr &&
+                          npx < ((size_t)1 << 28);
+    const size_t per_img_chained = can_fuse ? gf_per_img_chained(npx, np, nb, h, radius) : 0;
+    const size_t per_img_rw = gf_per_img_row_walk(npx, np, nb, h);
+    const size_t per_img = gf_per_img_two_kernel(npx, np);
+    const bool chained = can_fuse && debug_get(kDbgGfChained) &&
+                         workspace_bytes >= header + per_img_chained;
+    const bool fused = chained || (can_fuse && workspace_bytes >= header + per_img_rw);
+    const size_t per_img_fused = chained ? per_img_chained : per_img_rw;
+    if (!fused && workspace_bytes < header + per_img)
+        return fail(RF_E_WORKSPACE, "rf_gf_u8: workspace %zu B < %zu B needed for one image",
+                    workspace_bytes, header + per_img);
     // EXPERIMENT, off by default (debug option "gf_guide_cache"): iterated calls keep the guide half
     // of the per-pixel algebra (kGsFloats floats per pixel) from the first pass for the later ones,
     // which then box-sum only the 4 src quantities - 3x fewer VALU instructions in stage 1, but 36
@@ -935,13 +972,30 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
     // accesses), 8 x 4K grey, kernels alone: stage 1 of a later pass 1.085 ms against 1.044 ms
     // without the record, the pass that writes it 1.69 ms; C5 shard 11.4 against 14.0 GP/s
     // (profiles/r03_gf_guide_cache.md).  Kept as a switch so that the measurement can be repeated.
-    const size_t gs_bytes = npx * kGsFloats * sizeof(float);
+    const size_t gs_bytes = (npx * kGsFloats * sizeof(float) + 15) & ~(size_t)15;  // parts stay 16-byte aligned
     const bool keep_gs = iterations > 1 && debug_get(kDbgGfGuideCache) &&
                          workspace_bytes - header >= (fused ? per_img_fused : per_img) + gs_bytes;
-    const size_t per_img_used = (fused ? per_img_fused : per_img) + (keep_gs ? gs_bytes : 0);
+    // Iterated calls on 3-channel sources: an image whose channels are equal (the reference filters
+    // the CNN's grey map, /root/reference/README.md:66) passes from one pass to the next as ONE byte
+    // per pixel in the workspace instead of three in dst - the column walk writes a third of the
+    // bytes, the next pass's stage 1 (its one-byte-per-pixel instantiation) fetches 4 instead of 6
+    // bytes per pixel and row; the last pass writes dst.  Bytes identical (debug option
+    // "gf_no_compact" keeps the three-channel hand-off).
+    const size_t cmp_want = (npx + 15) & ~(size_t)15;
+    const size_t cmp_bytes =
+        (fused && src_cn == 3 && iterations > 1 && !debug_get(kDbgGfNoCompact) &&
+         workspace_bytes - header >= per_img_fused + (keep_gs ? gs_bytes : 0) + cmp_want)
+            ? cmp_want
+            : 0;
+    const size_t per_img_used =
+        (fused ? per_img_fused : per_img) + (keep_gs ? gs_bytes : 0) + cmp_bytes;
     int chunk = (int)std::min<size_t>((size_t)n, (workspace_bytes - header) / per_img_used);
     if (chunk > 16383)
         chunk = 16383;
+    // chained column walk: a part's images are dealt to 8 ticket queues (one per XCD), so parts of
+    // a multiple of 8 images - chunks of a multiple of 16 - load the queues evenly
+    if (chained && chunk >= 16 && n > chunk)
+        chunk &= ~15;
     const float eps_f = (float)eps;
     const int eps_small = eps < 1e-2;
     // stage-1 strips: stage1_threads x stage1_cols columns, 2r of them halo
@@ -964,11 +1018,27 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
     // One part = m images starting at i0, their scratch at ws, every launch on st.
     auto run_part = [&](int i0, int m, int m_fill, char *ws, hipStream_t st) {
         const int *colour = colour_all ? colour_all + i0 : nullptr;
-        // two-kernel form: [row sums (double)][alpha/beta]; fused form: [states (double)][alpha/beta]
+        // two-kernel form: [row sums (double)][alpha/beta]; row walk: [states (double)][alpha/beta];
+        // chained: [sync words][hand-off words][head sums][alpha/beta]
         double *rows = reinterpret_cast<double *>(ws);
         float *ab = reinterpret_cast<float *>(rows + (fused ? (size_t)m * np * nb * h
                                                             : (size_t)m * np * npx));
+        GfChain xc = {nullptr, nullptr, nullptr};
+        if (chained) {
+            xc.sync = reinterpret_cast<unsigned *>(ws);
+            xc.xst = reinterpret_cast<unsigned long long *>(ws + kGfSyncBytes);
+            double *head = reinterpret_cast<double *>(
+                ws + kGfSyncBytes + (size_t)m * gf_chain_xst_bytes(src_cn, nb, h, radius));
+            xc.head = head;
+            ab = reinterpret_cast<float *>(head + (size_t)m * np * h);
+            rows = nullptr;
+        }
         float *gs = keep_gs ? ab + (size_t)m * np * npx : nullptr;  // [m][h][kGsFloats][w]
+        // grey 3-channel images of an iterated call: the passes hand their result on as one byte per
+        // pixel (see cmp_bytes below)
+        uint8_t *cmp = cmp_bytes ? reinterpret_cast<uint8_t *>(ab + (size_t)m * np * npx) +
+                                       (keep_gs ? (size_t)m * gs_bytes : 0)
+                                 : nullptr;
         const uint8_t *g0 = guide + (size_t)i0 * npx * 3;
         uint8_t *d0 = dst + (size_t)i0 * npx * src_cn;
         // row segments: enough workgroups to fill 256 CUs, but segments no shorter than 2r+1.
@@ -1003,12 +1073,18 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
     do {                                                                                           \
         if (src_cn == 3) {                                                                         \
             hipLaunchKernelGGL((gf_stage1_kernel<3, 3, MODE>), ga3, dim3(stage1_threads(3)), 0, st, \
-                               g0, s0, ab, h, w, radius, eps_f, eps_small, seg_rows3, colour, gs); \
-            hipLaunchKernelGGL((gf_stage1_kernel<1, 3, MODE>), ga1, dim3(stage1_threads(1)), 0, st, \
-                               g0, s0, ab, h, w, radius, eps_f, eps_small, seg_rows1, colour, gs); \
+                               g0, s0, ab, h, w, radius, eps_f, eps_small, seg_rows3, colour, gs, 3); \
+            if (it > 0 && cmp != nullptr)                                                          \
+                hipLaunchKernelGGL((gf_stage1_kernel<1, 1, MODE>), ga1, dim3(stage1_threads(1)), 0, \
+                                   st, g0, cmp, ab, h, w, radius, eps_f, eps_small, seg_rows1,      \
+                                   colour, gs, 3);                                                 \
+            else                                                                                   \
+                hipLaunchKernelGGL((gf_stage1_kernel<1, 3, MODE>), ga1, dim3(stage1_threads(1)), 0, \
+                                   st, g0, s0, ab, h, w, radius, eps_f, eps_small, seg_rows1,       \
+                                   colour, gs, 3);                                                 \
         } else {                                                                                   \
             hipLaunchKernelGGL((gf_stage1_kernel<1, 1, MODE>), ga1, dim3(stage1_threads(1)), 0, st, \
-                               g0, s0, ab, h, w, radius, eps_f, eps_small, seg_rows1, colour, gs); \
+                               g0, s0, ab, h, w, radius, eps_f, eps_small, seg_rows1, colour, gs, 1); \
         }                                                                                          \
     } while (0)
             if (debug_get(kDbgGfExpSkip) & 1)
@@ -1022,8 +1098,9 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
 #undef RF_GF_STAGE1
             const int row_blocks = ceil_div(h, kBRows);
             if (fused) {
-                const GfFusedArgs fa = {ab, rows, g0, d0, m, h, w, nb, src_cn, colour, st,
-                                        debug_get(kDbgGfExpSkip)};
+                const GfFusedArgs fa = {ab, rows, g0, d0, m, h, w, nb, src_cn, colour, st, xc,
+                                        debug_get(kDbgGfExpSkip),
+                                        it + 1 < iterations ? cmp : nullptr};
                 fused_launch(fa);
                 continue;
             }

@@ -312,11 +312,81 @@ struct alignas(16) WalkLds {
 // 1-channel one) - 11 to 14 vector-memory instructions per sub-tile instead of 46.
 // spx = src bytes per pixel (1 or 3).  With spx = 3 an image whose flag colour[img] is 0 has three
 // equal channels: only its channel 0 is computed and the result byte is written three times.
+//
+// CHAINED form (xc.xst != nullptr; debug option "gf_chained", round 4; bit-identical but measured
+// slower than the row walk, see the end of this comment): there is no row-walk kernel.  The
+// row sum a block's chains start from is the one its LEFT neighbour's chains end with, so block b
+// takes the 64 (plane, row) sums of every sub-tile from block b - 1 and hands its own to block
+// b + 1 through memory; block 0 starts from the sums of the row's first 2R extended pixels
+// (gf_rowhead_kernel).  Every alpha/beta value is then read by the column walk only (entering and
+// leaving operand) instead of once more by a row walk: 16 B per pixel and pass less traffic.
+//   * Work items are handed out by ticket (one atomic counter per queue, queue = workgroup id mod 8
+//     = the XCD the hardware deals the workgroup to): queue q owns the images i = q (mod 8) of the
+//     launch and walks block-major through them, so a workgroup's left neighbour always holds an
+//     EARLIER ticket of the same queue - it is resident or finished, never waiting for a place:
+//     the chain cannot deadlock whatever the dispatch order.  Neighbours sit on one XCD (one L2).
+//   * Hand-off without flags or fences: a sum travels as two 8-byte words {low half, tag},
+//     {high half, tag'} - 8-byte accesses are single-copy atomic, so each word validates itself.
+//     The tags mix the launch's epoch (a device-side counter gf_rowhead_kernel increments, so a
+//     replayed graph gets fresh ones), the block, the sub-tile and the lane: what an earlier launch
+//     or another use of the workspace left in a slot does not match (2^-64 for arbitrary bytes).
+//     Stores and loads are agent-scope atomics: coherent across the XCDs' L2s by themselves.
+//     The consumer requests a sub-tile's words one iteration ahead and polls only if they are not
+//     there yet.
+//   * Measured at the C5 shard (128 x 4K, 3 passes; profiles/r04_gf_chained.md): the chained walk
+//     moves 63.4 B per pixel and pass (54.5 fetched) against 52.6 for row walk + column walk, and
+//     the step takes 79.5 ms against 72.5: a block runs two to three sub-tiles behind its left
+//     neighbour (hand-off latency + the one-iteration prefetch), so the 128-byte lines that
+//     neighbouring blocks' misaligned 256-byte operand runs share - and the leaving operands, which
+//     are the entering operands of the blocks 5 and 6 places to the left - are no longer found in
+//     the XCD's L2, which the lock-step walk of the row-walk form gets for free.
+//   * Polls are bounded: a consumer whose words never arrive sets xc.sync[8] and goes on with what
+//     it has (wrong bytes instead of a hung device); tests read the word.
+// sub-tile slots per block of the chained hand-off, and the bytes of one image's hand-off buffer
+__host__ __device__ inline int gf_chain_nsub(int h, int radius)
+{
+    const int m = (radius + 15) / 16;
+    return ((h + 4 * radius - 1) / (2 * radius)) * 2 * m;
+}
+struct GfChain {
+    const double *head;        // [img * np + plane][h]: sum of the row's first 2R extended pixels
+    unsigned long long *xst;   // [(img * spx + ch) * nb + b][nsub_all][64]: 16-byte slots {low, tag0, high, tag1}
+    unsigned *sync;            // [0..7] tickets, [8] error flag, [9] epoch
+};
+
+typedef unsigned gf_u32x4 __attribute__((ext_vector_type(4)));
+
+// The two tags of a hand-off slot: independent 32-bit mixes (bijective finalisers over differently
+// combined inputs), so that a slot written for any other (epoch, block, sub-tile, lane) - an earlier
+// launch, another layout of the same workspace - matches with probability 2^-64, and a slot of the
+// same place from an earlier launch (only the epoch differs) never does.
+__device__ __forceinline__ unsigned gf_chain_tag0(unsigned seed, unsigned j, unsigned lane)
+{
+    unsigned x = seed ^ (j * 0x85ebca77u) ^ (lane * 0xc2b2ae3du);
+    x ^= x >> 15;
+    x *= 0x2c1b3c6du;
+    x ^= x >> 12;
+    x *= 0x297a2d39u;
+    x ^= x >> 15;
+    return x;
+}
+__device__ __forceinline__ unsigned gf_chain_tag1(unsigned seed, unsigned j, unsigned lane)
+{
+    unsigned x = seed + j * 0x27d4eb2fu + lane * 0x165667b1u;
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+
 template <int R>
 __global__ __launch_bounds__(128, (R <= 64 ? 2 : 1)) void gf_colwalk_kernel(
     const float *__restrict__ ab, const double *__restrict__ states,
     const uint8_t *__restrict__ guide, uint8_t *__restrict__ dst, int h, int w, int nb,
-    int n_pairs, int spx, const int *__restrict__ colour)
+    int n_pairs, int spx, const int *__restrict__ colour, const GfChain xc,
+    uint8_t *__restrict__ compact)
 {
     using G = WalkGeom<R>;
     constexpr int M = G::M, T = G::T;
@@ -328,28 +398,45 @@ __global__ __launch_bounds__(128, (R <= 64 ? 2 : 1)) void gf_colwalk_kernel(
     // and walks pair by pair through the channels: the channels of a block share their guide rows
     // in that XCD's L2, and the channel items of grey 3-channel images that exit at once are spread
     // evenly over the XCDs
-    const int per_xcd = (n_pairs + 7) >> 3;
-    const int q = (int)(blockIdx.x >> 3);
-    const int pair = (int)(blockIdx.x & 7) * per_xcd + q / spx;
-    if (q / spx >= per_xcd || pair >= n_pairs)
-        return;
-    const int s_ch = q % spx;
-    const int b = pair % nb;
-    const int img = pair / nb;
-    const bool grey3 = spx == 3 && colour[img] == 0;  // three equal channels: channel 0 stands for all
-    if (grey3 && s_ch > 0)
-        return;
-
     __shared__ WalkLds<T> lds[2];
     __shared__ double sumx[64];
     __shared__ int turn;  // next sub-tile whose column phase may run
+    __shared__ int ticket;
 
+    const bool chained = xc.xst != nullptr;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     WalkLds<T> &L = lds[wv];
-    if (threadIdx.x == 0)
+    if (threadIdx.x == 0) {
         turn = 0;
-    __syncthreads();  // the only barrier: both waves see turn = 0
+        if (chained)
+            ticket = (int)atomicAdd(&xc.sync[blockIdx.x & 7], 1u);
+    }
+    __syncthreads();  // the only barrier: both waves see turn = 0 (and the ticket)
+    int s_ch, b, img;
+    if (chained) {
+        const int qx = (int)(blockIdx.x & 7), m_img = n_pairs / nb;
+        const int items = ((m_img - qx + 7) >> 3) * spx;  // (image, channel) items of this queue
+        const int t = ticket;
+        if (items <= 0 || t >= items * nb)
+            return;
+        b = t / items;
+        const int k = t - b * items;
+        img = qx + 8 * (k / spx);
+        s_ch = k % spx;
+    } else {
+        const int per_xcd = (n_pairs + 7) >> 3;
+        const int q = (int)(blockIdx.x >> 3);
+        const int pair = (int)(blockIdx.x & 7) * per_xcd + q / spx;
+        if (q / spx >= per_xcd || pair >= n_pairs)
+            return;
+        s_ch = q % spx;
+        b = pair % nb;
+        img = pair / nb;
+    }
+    const bool grey3 = spx == 3 && colour[img] == 0;  // three equal channels: channel 0 stands for all
+    if (grey3 && s_ch > 0)
+        return;  // (chained: nobody waits for a skipped channel's blocks, its neighbours skip too)
 
     const int cc = lane & 15;                    // column role: lane = plane * 16 + column
     const int cp = lane / T, cl = lane - cp * T;  // chain role (lane < 4T): plane, row
@@ -360,6 +447,8 @@ __global__ __launch_bounds__(128, (R <= 64 ? 2 : 1)) void gf_colwalk_kernel(
     const double *stg = states + ((size_t)img * np + 4 * s_ch) * nb * h;  // their states
     const uint8_t *gimg = guide + (size_t)img * npx * 3;
     uint8_t *dimg = dst + (size_t)img * npx * spx;
+    // a grey 3-channel image of an iterated call hands its result on as one byte per pixel
+    uint8_t *cimg = (grey3 && compact != nullptr) ? compact + (size_t)img * npx : nullptr;
     // RowSum at output column o = 16 b + cc (cc >= 1):  + ext[o + 2r] - ext[o - 1], ext[i] = S[bi(i - r)]
     // per-lane BYTE offsets of the float4 pixel from the wave-uniform base abg of the channel's
     // plane group ([h][w][4] floats; 32 bits: the host admits images below 2^28 pixels here)
@@ -367,7 +456,10 @@ __global__ __launch_bounds__(128, (R <= 64 ? 2 : 1)) void gf_colwalk_kernel(
     const uint32_t ol =
         16u * (uint32_t)border_interpolate(b * kSB + cc - 1 - R, w, RF_BORDER_REFLECT);
     const char *abgb = reinterpret_cast<const char *>(abg);
-    const double *Ps = stg + ((size_t)min(cp, 3) * nb + b) * h;
+    // start of the lane's row chain: the stored state at column 16 b (row-walk form), or - chained -
+    // the sum at column 16 b - 1: for block 0 the head sums, else what block b - 1 published
+    const double *Ps = chained ? xc.head + ((size_t)img * np + 4 * s_ch + min(cp, 3)) * h
+                               : stg + ((size_t)min(cp, 3) * nb + b) * h;
     const double scale = 1.0 / (double)(KS * KS);
     const int total = h + 2 * R;  // padded rows
     const int jmax = total - 1;
@@ -381,6 +473,29 @@ __global__ __launch_bounds__(128, (R <= 64 ? 2 : 1)) void gf_colwalk_kernel(
         nsub = full * 2 * M + cnt;
     }
     const uint32_t gbytes = (uint32_t)(npx * 3);
+    // chained hand-off: sums in from block b - 1, out to block b + 1; nsub_all = sub-tile slots per block
+    const int nsub_all = gf_chain_nsub(h, R);
+    const size_t item_blk = ((size_t)img * spx + s_ch) * nb + b;
+    const bool take = chained && b > 0, give = chained && b + 1 < nb;
+    // (buffer descriptors over one block's slots each: 16-byte sc1 loads / stores, L1-bypassing and
+    //  write-through; the base must be wave-uniform registers)
+    const unsigned slot_bytes = (unsigned)nsub_all * 64u * 16u;
+    auto block_rsrc = [&](size_t blk) __attribute__((always_inline)) {
+        const unsigned long long a_ =
+            (unsigned long long)(uintptr_t)xc.xst + (unsigned long long)blk * slot_bytes;
+        const unsigned lo_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a_);
+        const unsigned hi_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a_ >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(uintptr_t)(((unsigned long long)hi_ << 32) | lo_), 0, (int)slot_bytes, 0x00020000);
+    };
+    const auto rs_in = block_rsrc(take ? item_blk - 1 : item_blk);
+    const auto rs_out = block_rsrc(item_blk);
+    const unsigned epoch = chained ? xc.sync[9] : 0u;
+    const unsigned sa_in = (epoch * 0x9e3779b1u) ^ ((unsigned)(item_blk - 1) * 0x7feb352du);
+    const unsigned sb_in = (epoch * 0x632be5abu) + ((unsigned)(item_blk - 1) * 0x9e3779b1u);
+    const unsigned sa_out = (epoch * 0x9e3779b1u) ^ ((unsigned)item_blk * 0x7feb352du);
+    const unsigned sb_out = (epoch * 0x632be5abu) + ((unsigned)item_blk * 0x9e3779b1u);
+    gf_u32x4 xw = {0u, 0u, 0u, 0u};  // the prefetched slot {low, tag0, high, tag1} of the next sub-tile
 
     const int r4 = lane >> 4;            // loader role: row of a group of four, column cc
     const int fr = lane >> 2, qd = lane & 3;  // flush role: row of the sub-tile, quad of columns
@@ -414,8 +529,34 @@ __global__ __launch_bounds__(128, (R <= 64 ? 2 : 1)) void gf_colwalk_kernel(
             pe[i] = *reinterpret_cast<const float4 *>(abgb + (oe + ro));
             pl[i] = *reinterpret_cast<const float4 *>(abgb + (ol_ + ro));
         }
-        if (chain)
+        if (chain && !take)
             pst = Ps[L.rowtab[slot][cl]];
+    };
+    // chained, b > 0: request the left neighbour's slot of sub-tile jj (two self-validating words)
+    auto take_issue = [&](int jj) __attribute__((always_inline)) {
+        xw = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (jj * 64 + lane) * 16, 0, /*sc1*/ 16);
+    };
+    // ... and use it: poll until both tags are the ones block b - 1 writes for sub-tile jj
+    auto take_sums = [&](int jj) __attribute__((always_inline)) -> double {
+        const unsigned t0 = gf_chain_tag0(sa_in, (unsigned)jj, (unsigned)lane),
+                       t1 = gf_chain_tag1(sb_in, (unsigned)jj, (unsigned)lane);
+        int polls = 0;
+        while (__builtin_amdgcn_ballot_w64(chain && (xw.y != t0 || xw.w != t1)) != 0ull) {
+            if (++polls > (1 << 20)) {  // seconds: the neighbour is gone - flag it, do not hang
+                if (lane == 0)
+                    atomicOr(&xc.sync[8], 1u);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(16);
+            xw = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (jj * 64 + lane) * 16, 0, 16);
+        }
+        return __longlong_as_double((long long)(((unsigned long long)xw.z << 32) | xw.x));
+    };
+    auto give_sums = [&](int jj, double v) __attribute__((always_inline)) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+        const gf_u32x4 o = {(unsigned)bits, gf_chain_tag0(sa_out, (unsigned)jj, (unsigned)lane),
+                            (unsigned)(bits >> 32), gf_chain_tag1(sb_out, (unsigned)jj, (unsigned)lane)};
+        __builtin_amdgcn_raw_buffer_store_b128(o, rs_out, (jj * 64 + lane) * 16, 0, 16);
     };
     // guide bytes of the lane's output pixels: row y0 + fr, columns 16 b + 4 qd .. + 3 (12 bytes)
     auto guide_fetch = [&](int y0) __attribute__((always_inline)) {
@@ -454,7 +595,9 @@ __global__ __launch_bounds__(128, (R <= 64 ? 2 : 1)) void gf_colwalk_kernel(
             return;
         const uint32_t pix = (uint32_t)y * w + x;
         if (x + 3 < w && (grey3 || spx == 1)) {
-            if (grey3) {  // every result byte three times: 12 contiguous bytes
+            if (cimg != nullptr) {
+                __builtin_memcpy(cimg + pix, &o4, 4);
+            } else if (grey3) {  // every result byte three times: 12 contiguous bytes
                 const uint32_t b0 = o4 & 0xff, b1 = (o4 >> 8) & 0xff, b2 = (o4 >> 16) & 0xff,
                                b3 = o4 >> 24;
                 const uint32_t d[3] = {b0 * 0x010101u | (b1 << 24), b1 * 0x0101u | (b2 * 0x0101u << 16),
@@ -470,7 +613,9 @@ __global__ __launch_bounds__(128, (R <= 64 ? 2 : 1)) void gf_colwalk_kernel(
             if (x + i >= w)
                 break;
             const uint8_t v = (uint8_t)(o4 >> (8 * i));
-            if (grey3) {
+            if (cimg != nullptr) {
+                cimg[pix + i] = v;
+            } else if (grey3) {
                 dimg[(size_t)(pix + i) * 3 + 0] = v;
                 dimg[(size_t)(pix + i) * 3 + 1] = v;
                 dimg[(size_t)(pix + i) * 3 + 2] = v;
@@ -489,6 +634,8 @@ __global__ __launch_bounds__(128, (R <= 64 ? 2 : 1)) void gf_colwalk_kernel(
         rowtab(0, pbase + G::start(jp));
         wave_lds_fence();
         fetch(0);
+        if (take)
+            take_issue(j);
     }
     int slot = 0;
     for (; j < nsub;) {
@@ -513,15 +660,18 @@ __global__ __launch_bounds__(128, (R <= 64 ? 2 : 1)) void gf_colwalk_kernel(
                 L.u.st.L[3 * T + r][cc] = pl[i].w;
             }
         }
-        double s = pst;
+        double s = take ? take_sums(j) : pst;
         RF_STAMP(1);  // wait for the operands (and every older store)
         store_pending();
         st_tj = 0;
         wave_lds_fence();
         if (!fill)
             guide_fetch(i0 - 2 * R);
-        if (jn < nsub)
+        if (jn < nsub) {
             fetch(slot ^ 1);
+            if (take)
+                take_issue(jn);
+        }
         RF_STAMP(2);
         if (chain) {
             // all operand differences first (independent LDS reads and conversions), then the
@@ -530,12 +680,20 @@ __global__ __launch_bounds__(128, (R <= 64 ? 2 : 1)) void gf_colwalk_kernel(
 #pragma unroll
             for (int c = 1; c < kSB; c++)
                 d[c] = (double)L.u.st.E[lane][c] - (double)L.u.st.L[lane][c];
+            if (chained) {
+                // s is the sum at column 16 b - 1: one more step to column 16 b.  At the row's
+                // first output column nothing leaves the window yet (block 0: s = sum of ext[0 .. 2R-1])
+                const double d0 = (double)L.u.st.E[lane][0] - (b == 0 ? 0.0 : (double)L.u.st.L[lane][0]);
+                s += d0;
+            }
             L.Rt[cp * kSB][cl] = s;
 #pragma unroll
             for (int c = 1; c < kSB; c++) {
                 s += d[c];
                 L.Rt[cp * kSB + c][cl] = s;
             }
+            if (give)
+                give_sums(j, s);
         }
         wave_lds_fence();
         RF_STAMP(3);
@@ -623,6 +781,48 @@ __global__ __launch_bounds__(128, (R <= 64 ? 2 : 1)) void gf_colwalk_kernel(
 #endif
 }
 
+// Chained column walk, block 0: head[img * np + plane][row] = ext[0] + ... + ext[2R-1] added in this
+// order from 0.0 (RowSum<float,double>'s first 2R steps; ext[i] = S[bi(i - R)]), i.e. the running sum
+// one step before the row's first output.  lane = row, the four planes of a src channel together
+// (float4 pixels).  grid (ceil(h / 64), images x src channels).  Thread 0 of the launch also opens
+// the launch's ticket queues and advances the epoch of the hand-off tags (sync: see GfChain).
+template <int kHeaderOnly = 0>  // (a template only so that every unit including this header may hold it)
+__global__ __launch_bounds__(64) void gf_rowhead_kernel(const float *__restrict__ ab,
+                                                        double *__restrict__ head, int h, int w,
+                                                        int radius, int spx,
+                                                        const int *__restrict__ colour,
+                                                        unsigned *__restrict__ sync)
+{
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            sync[q] = 0u;  // (word 8, the error flag, stays: it is sticky until the caller clears it)
+        sync[9] = sync[9] + 1u;
+    }
+    const int img = blockIdx.y / spx, ch = blockIdx.y - img * spx;
+    if (spx == 3 && ch > 0 && colour[img] == 0)
+        return;  // grey 3-channel image: channel 0 stands for all
+    const int row = blockIdx.x * 64 + threadIdx.x;
+    if (row >= h)
+        return;
+    const int np = 4 * spx;
+    const float4 *S4 = reinterpret_cast<const float4 *>(ab + ((size_t)img * np + 4 * ch) * h * w) +
+                       (size_t)row * w;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int i = 0; i < 2 * radius; i++) {
+        const float4 v = S4[border_interpolate(i - radius, w, RF_BORDER_REFLECT)];
+        s0 += (double)v.x;
+        s1 += (double)v.y;
+        s2 += (double)v.z;
+        s3 += (double)v.w;
+    }
+    double *H = head + ((size_t)img * np + 4 * ch) * h + row;
+    H[0] = s0;
+    H[(size_t)h] = s1;
+    H[(size_t)2 * h] = s2;
+    H[(size_t)3 * h] = s3;
+}
+
 // Launches of the fused stage 2 for one radius (defined per radius in rf_gf_fused_*.hip).
 struct GfFusedArgs {
     const float *ab;
@@ -632,7 +832,9 @@ struct GfFusedArgs {
     int m, h, w, nb, src_cn;
     const int *colour;
     hipStream_t stream;
+    GfChain chain;  // xst == nullptr: row-walk form (gf_rowstate_kernel + stored states)
     int exp_skip;  // timing experiments only (debug option "gf_exp_skip"): bit 1 no row states, bit 2 no column walk
+    uint8_t *compact;  // not the last pass of an iterated call: grey 3-channel images go here, 1 B per pixel
 };
 typedef void (*GfFusedLaunch)(const GfFusedArgs &);
 GfFusedLaunch gf_fused_launcher(int radius);  // nullptr outside 1 .. kGfFusedMaxRadius
@@ -642,15 +844,29 @@ void gf_fused_launch(const GfFusedArgs &a)
 {
     const int row_blocks = (a.h + kBRows - 1) / kBRows;
     const int np = 4 * a.src_cn;
+    const int pairs = a.m * a.nb;
+    if (a.chain.xst != nullptr) {
+        // chained column walk: head sums (which also resets the tickets and advances the epoch),
+        // then 8 queues of ceil(m / 8) * src_cn * nb tickets each
+        const int hb = (a.h + 63) / 64;
+        hipLaunchKernelGGL(gf_rowhead_kernel<0>, dim3((unsigned)hb, (unsigned)(a.m * a.src_cn)), dim3(64), 0,
+                           a.stream, a.ab, const_cast<double *>(a.chain.head), a.h, a.w, R, a.src_cn,
+                           a.colour, a.chain.sync);
+        if (!(a.exp_skip & 4))
+            hipLaunchKernelGGL((gf_colwalk_kernel<R>),
+                               dim3(8u * (unsigned)((a.m + 7) / 8) * a.src_cn * a.nb), dim3(128), 0,
+                               a.stream, a.ab, a.states, a.guide, a.dst, a.h, a.w, a.nb, pairs,
+                               a.src_cn, a.colour, a.chain, a.compact);
+        return;
+    }
     if (!(a.exp_skip & 2))
         hipLaunchKernelGGL((gf_rowstate_kernel<R>), dim3((unsigned)(a.m * a.src_cn * row_blocks)),
                            dim3(256), 0, a.stream, a.ab, a.states, a.h, a.w, row_blocks, np, a.colour,
                            np, a.nb);
-    const int pairs = a.m * a.nb;
     if (!(a.exp_skip & 4))
         hipLaunchKernelGGL((gf_colwalk_kernel<R>), dim3(8u * (unsigned)((pairs + 7) / 8) * a.src_cn),
                        dim3(128), 0, a.stream, a.ab, a.states, a.guide, a.dst, a.h, a.w, a.nb, pairs,
-                       a.src_cn, a.colour);
+                       a.src_cn, a.colour, GfChain{nullptr, nullptr, nullptr}, a.compact);
 }
 
 }  // namespace rf
