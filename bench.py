@@ -171,10 +171,47 @@ def synth_batch(torch, n, h, w, seed, device):
     return joint.contiguous(), src.contiguous()
 
 
-def flat_guide(scene):
-    """Piecewise-constant ("L1-flattened") guidance of BASELINE config C5: the scene posterised to
-    8 levels per channel (large flat regions with sharp steps), generated on the device."""
-    return (scene // 32) * 32 + 16
+def flat_guide(scene, seed=9000):
+    """Piecewise-constant ("L1-flattened") guidance of BASELINE config C5 as SURVEY.md 8(d)
+    specifies it: seeded Voronoi cells (200 - 2,000 regions by image size: about one per 8,192
+    pixels), each of one flat colour - the scene's colour at the cell's seed point, so the
+    regions follow the scene the src map belongs to - plus a +-1 dither, generated on the device.
+    The seed points are one per cell of a jittered grid and a pixel takes the nearest seed of the
+    3 x 3 grid cells around its own (the exact Voronoi partition of those seeds but for rare
+    slivers whose nearest seed lies two cells away)."""
+    import torch
+    n, h, w, _ = scene.shape
+    dev = scene.device
+    regions = int(min(2000, max(200, h * w / 8192.0)))
+    regions = max(1, min(regions, (h * w) // 16))
+    gw = max(1, int(round((regions * w / float(h)) ** 0.5)))
+    gh = max(1, int(round(regions / float(gw))))
+    gen = torch.Generator(device=dev)
+    out = torch.empty_like(scene)
+    py = torch.arange(h, device=dev, dtype=torch.float32)
+    px = torch.arange(w, device=dev, dtype=torch.float32)
+    cy = (torch.arange(h, device=dev) * gh) // h
+    cx = (torch.arange(w, device=dev) * gw) // w
+    for i in range(n):
+        gen.manual_seed(seed + i)
+        sy = (torch.arange(gh, device=dev)[:, None] + torch.rand((gh, gw), device=dev, generator=gen)) * (h / float(gh))
+        sx = (torch.arange(gw, device=dev)[None, :] + torch.rand((gh, gw), device=dev, generator=gen)) * (w / float(gw))
+        colour = scene[i][sy.long().clamp_(0, h - 1), sx.long().clamp_(0, w - 1)].reshape(-1, 3)
+        best = torch.full((h, w), float("inf"), device=dev)
+        lab = torch.zeros((h, w), dtype=torch.long, device=dev)
+        for dy in (-1, 0, 1):
+            ny = (cy + dy).clamp_(0, gh - 1)
+            for dx in (-1, 0, 1):
+                nx = (cx + dx).clamp_(0, gw - 1)
+                d = (py[:, None] - sy[ny[:, None], nx[None, :]]) ** 2
+                d += (px[None, :] - sx[ny[:, None], nx[None, :]]) ** 2
+                upd = d < best
+                best = torch.where(upd, d, best)
+                lab = torch.where(upd, ny[:, None] * gw + nx[None, :], lab)
+        img = colour[lab].to(torch.int16)
+        img += torch.randint(-1, 2, (h, w, 3), device=dev, generator=gen, dtype=torch.int16)
+        out[i] = img.clamp_(0, 255).to(torch.uint8)
+    return out
 
 
 def usable_cores():
@@ -511,6 +548,77 @@ def live_traffic(args, n, h, w, deadline_s=150.0):
                    % (got["FETCH_SIZE"], got["WRITE_SIZE"]))
 
 
+def short_kernel_name(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "").replace("rf::", "")
+    cut = name.find("(")
+    return name[:cut] if cut > 0 else name
+
+
+def live_traffic_config(cfg, batch, deadline_s=90.0):
+    """HBM-side bytes of ONE step of another BASELINE configuration (c3 / c5), per kernel: this
+    script run twice as a child under `rocprofv3 --pmc` (FETCH_SIZE, then WRITE_SIZE; separate
+    passes, the program directly after `--`), one step each, no warm-up (counters do not need one).
+    Every dispatch of a library kernel (`rf::`) of that step is added up per kernel name; units and
+    the gfx950 correction as in `live_traffic` (KiB; FETCH_SIZE doubled - tools/microbench/
+    fetch_calib.hip measures 2.00 for 1-, 4-, 8-, 12- and 16-byte loads).  Returns
+    ({"traffic", "traffic_source", "kernels": {name: {"fetch_bytes", "write_bytes", "launches"}}},
+    None) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="rf_bench_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", RF_BENCH_CHILD="1")
+    for key in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(key, None)
+    kernels = {}
+    t_end = time.time() + deadline_s
+    try:
+        for counter, field in (("FETCH_SIZE", "fetch_bytes"), ("WRITE_SIZE", "write_bytes")):
+            out_dir = os.path.join(tmp, counter.lower())
+            cmd = [prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out_dir,
+                   "--", sys.executable, os.path.abspath(__file__), "--config", cfg,
+                   "--batch", str(batch), "--steps", "1", "--warmup", "0", "--cpu-seconds", "0",
+                   "--no-extras", "--traffic", "off"]
+            left = t_end - time.time()
+            if left < 15:
+                return None, "no time left for the %s pass" % counter
+            try:
+                p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE,
+                                   stderr=subprocess.PIPE, timeout=left)
+            except subprocess.TimeoutExpired:
+                return None, "the %s pass exceeded its time" % counter
+            files = glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True)
+            if p.returncode != 0 or not files:
+                return None, "the %s pass failed (rc %d)" % (counter, p.returncode)
+            scale = 2.0 * 1024.0 if counter == "FETCH_SIZE" else 1024.0
+            seen = set()
+            with open(files[0], newline="") as fh:
+                for r in csv.DictReader(fh):
+                    if r.get("Counter_Name") != counter or "rf::" not in r.get("Kernel_Name", ""):
+                        continue
+                    k = kernels.setdefault(short_kernel_name(r["Kernel_Name"]),
+                                           {"fetch_bytes": 0.0, "write_bytes": 0.0, "launches": 0})
+                    k[field] += float(r["Counter_Value"]) * scale
+                    if counter == "FETCH_SIZE" and r["Dispatch_Id"] not in seen:
+                        seen.add(r["Dispatch_Id"])
+                        k["launches"] += 1
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    if not kernels:
+        return None, "no library kernel in the counter files"
+    total = sum(k["fetch_bytes"] + k["write_bytes"] for k in kernels.values())
+    return ({"traffic": total,
+             "traffic_source": "measured by this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child "
+                               "passes of one step of `bench.py --config %s --batch %d` (FETCH_SIZE "
+                               "doubled for gfx950), every dispatch of a library kernel added up"
+                               % (cfg, batch),
+             "kernels": kernels}, None)
+
+
 def run_rank(args):
     stub = os.environ.get("RF_BENCH_STUB") == "1"
     if stub and os.environ.get("RF_BENCH_STUB_FAIL_RANK") == os.environ.get("RANK", "0"):
@@ -611,9 +719,31 @@ def run_rank(args):
                            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
                                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                         "algorithmic_bytes_per_px": w2l.bytes_per_px}}
+            px_step = w2l.pixels
             del w2l
             rf.ops.release_workspaces()
             torch.cuda.empty_cache()
+            # memory-side traffic of one step of this configuration, per kernel (two --pmc child
+            # passes; never fatal, skipped when profiled / told not to / out of its time)
+            if args.traffic in ("auto", "live") and (args.traffic == "live" or (
+                    not being_profiled() and os.environ.get("RF_BENCH_CHILD") != "1")):
+                try:
+                    rec, why = live_traffic_config(cfg, nb)
+                except Exception as exc:              # noqa: BLE001 - a measurement aid
+                    rec, why = None, repr(exc)
+                if rec is None:
+                    sys.stderr.write("bench.py: %s traffic measurement unavailable: %s\n" % (key, why))
+                    extras[key]["roofline"].update({"traffic": None, "traffic_source": why})
+                else:
+                    for k in rec["kernels"].values():
+                        k["bytes_per_px"] = (k["fetch_bytes"] + k["write_bytes"]) / px_step
+                    extras[key]["roofline"].update(
+                        {"traffic": rec["traffic"], "traffic_source": rec["traffic_source"],
+                         "traffic_bytes_per_px": rec["traffic"] / px_step,
+                         "traffic_kernels": rec["kernels"]})
+                    if k2 == "gf3":   # a step is three passes over every pixel
+                        extras[key]["roofline"]["traffic_bytes_per_px_per_pass"] = (
+                            rec["traffic"] / px_step / 3.0)
 
     if world > 1:
         import torch.distributed as dist

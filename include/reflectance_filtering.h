@@ -79,6 +79,11 @@ int rf_jbf_u8(const uint8_t *joint, const uint8_t *src, uint8_t *dst, int n, int
  *   guide  n*h*w*3        device (guide_cn must be 3: cv2.imread always yields 3 channels)
  *   src    n*h*w*src_cn   device, src_cn in {1,3}
  *   dst    n*h*w*src_cn   device; may alias src
+ *   radius 0..4096 (int(sigma_spatial) is a free parameter of the reference's tool): radii up to
+ *   120 run the 8-bit kernels (exact uint32 window sums); larger ones run the float kernels of
+ *   rf_gf_f32 on float copies of the images kept in the workspace, each pass rounded to uint8 like
+ *   convertTo(CV_8U) - the same bytes (on 8-bit data the float path's double window sums are the
+ *   same exact integers).  rf_gf_workspace_bytes sizes the workspace for the radius it is given.
  *   iterations >= 1: the filter is applied `iterations` times with the same guide, the uint8
  *   result of one pass being the src of the next (the reference's "3x GF" chain of CLI runs).
  *   workspace: device scratch of at least rf_gf_workspace_bytes(1, ...) bytes; larger
@@ -117,8 +122,9 @@ int rf_cnn_reflectance_u8(const uint8_t *bgr, float *r_out, uint8_t *r_u8_out, i
  * done once per set of weights; rf_cnn_reflectance_packed_u8 is forward() on a loaded net
  * (:86-92).  The library keeps no state for this pair, so it can be captured into a HIP graph and
  * used from any number of streams.  rf_cnn_reflectance_u8 above is pack + forward in one call,
- * with the packed copy in a small library-owned table keyed by (device, stream); its FIRST call on
- * a stream allocates and is therefore refused (RF_E_UNSUPPORTED) while that stream is captured.
+ * with the packed copy in a small library-owned table keyed by (device, stream) whose slots are
+ * recycled; it is refused (RF_E_UNSUPPORTED) on a stream that is being captured - a graph would
+ * keep a slot's address after the slot has moved on - so graphs use the pair.
  *   weights  4513 float32 on the device, layout as above
  *   packed   RF_CNN_NPACKED float32 on the device, caller-owned: the weights in the order the
  *            kernel streams them, the 160 fuse weights twice each (opaque; valid for this library

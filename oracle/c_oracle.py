@@ -17,6 +17,14 @@ BORDER_CONSTANT, BORDER_REPLICATE, BORDER_REFLECT, BORDER_WRAP, BORDER_REFLECT_1
 BORDER_DEFAULT = BORDER_REFLECT_101
 FLAG_TRUE_DIVISION = 1
 CNN_NPARAMS = 4513
+# rf_oracle.c RFO_VAR_*: the recalled choices a real OpenCV / Caffe could overturn (0 = the restatement
+# the kernels follow); name -> bit, grouped by the operator each one affects
+VARIANTS = {"jbf_true_division": 0x01, "jbf_fma": 0x02, "gf_diag_add_eps": 0x04,
+            "gf_float_boxsum": 0x08, "gf_fma": 0x10, "cnn_sigmoid_tanh": 0x20,
+            "cnn_gemm_no_fma": 0x40}
+VARIANTS_OF = {"jbf": ("jbf_true_division", "jbf_fma"),
+               "gf": ("gf_diag_add_eps", "gf_float_boxsum", "gf_fma"),
+               "cnn": ("cnn_sigmoid_tanh", "cnn_gemm_no_fma")}
 
 
 def build(force=False):
@@ -38,6 +46,10 @@ def lib():
         u8p = ctypes.POINTER(ctypes.c_uint8)
         f32p = ctypes.POINTER(ctypes.c_float)
         i32p = ctypes.POINTER(ctypes.c_int)
+        L.rfo_set_variants.argtypes = [ctypes.c_uint]
+        L.rfo_set_variants.restype = ctypes.c_uint
+        L.rfo_get_variants.argtypes = []
+        L.rfo_get_variants.restype = ctypes.c_uint
         L.rfo_border_interpolate.argtypes = [ctypes.c_int] * 3
         L.rfo_border_interpolate.restype = ctypes.c_int
         L.rfo_jbf_radius.argtypes = [ctypes.c_int, ctypes.c_double]
@@ -67,6 +79,28 @@ def lib():
         L.rfo_cnn_reflectance_u8.restype = ctypes.c_int
         _lib = L
     return _lib
+
+
+class variants:
+    """``with variants("gf_fma", "gf_diag_add_eps"): ...`` runs the oracle with those recalled
+    choices flipped (names of VARIANTS, or a mask); the previous mask is restored on exit."""
+
+    def __init__(self, *names):
+        self.mask = 0
+        for n in names:
+            self.mask |= n if isinstance(n, int) else VARIANTS[n]
+
+    def __enter__(self):
+        self.prev = lib().rfo_set_variants(self.mask)
+        return self
+
+    def __exit__(self, *exc):
+        lib().rfo_set_variants(self.prev)
+        return False
+
+
+def variant_names(mask):
+    return [n for n, b in VARIANTS.items() if mask & b]
 
 
 def _u8(a):

@@ -29,6 +29,9 @@
  * (c) the reference's own Python helpers for every step the reference does
  * itself (tests/golden/).
  *
+ * The recalled choices a real OpenCV / Caffe could overturn each have a switch (RFO_VAR_*,
+ * rfo_set_variants): tools/t2_report.py tries the combinations and names the matching one.
+ *
  * Build: gcc -O2 -std=c11 -ffp-contract=off -fno-fast-math -fopenmp -shared -fPIC
  * (-ffp-contract=off matters: every mul/add below is a separately rounded
  * IEEE-754 binary32/binary64 operation, as in an SSE2 build of OpenCV).
@@ -49,6 +52,30 @@
 #define RFO_BORDER_REFLECT_101 4
 
 #define RFO_FLAG_TRUE_DIVISION 1 /* dst = sum / wsum instead of sum * (1.f / wsum) */
+
+/*
+ * VARIANTS.  The choices below were RECALLED from the upstream sources, not read: a real OpenCV /
+ * Caffe build may have made the other one (another version, an FMA-contracting compiler, another
+ * dispatch path).  Each has a switch, so that tools/t2_report.py can try the combinations against
+ * a real cv2 / caffe and name the one that matches bit for bit; the default (0) is the restatement
+ * the HIP kernels and the frozen vectors follow.  Process-global; set by rfo_set_variants().
+ */
+#define RFO_VAR_JBF_TRUE_DIVISION 0x01 /* joint bilateral: dst = sum / wsum (not sum * (1.f / wsum)) */
+#define RFO_VAR_JBF_FMA 0x02           /* joint bilateral: sum = fma(w, src, sum) (an FMA build) */
+#define RFO_VAR_GF_DIAG_ADD_EPS 0x04   /* guided: cov_ii = (mean(I*I) - mean*mean) + eps, not sub_mad(-eps) */
+#define RFO_VAR_GF_FLOAT_BOXSUM 0x08   /* guided: boxFilter running sums in float, not double */
+#define RFO_VAR_GF_FMA 0x10            /* guided: the mul/sub_mul/add_mul/sub_mad helpers contracted to FMAs */
+#define RFO_VAR_CNN_SIGMOID_TANH 0x20  /* CNN: sigmoid = 0.5 * tanh(0.5 x) + 0.5 (later BVLC master) */
+#define RFO_VAR_CNN_GEMM_NO_FMA 0x40   /* CNN: dot products as separately rounded mul and add */
+#define RFO_VAR_ALL 0x7f
+static unsigned g_rfo_variants = 0;
+unsigned rfo_set_variants(unsigned mask)
+{
+    unsigned old = g_rfo_variants;
+    g_rfo_variants = mask & RFO_VAR_ALL;
+    return old;
+}
+unsigned rfo_get_variants(void) { return g_rfo_variants; }
 
 int rfo_version(void) { return 1; }
 
@@ -180,6 +207,9 @@ int rfo_jbf_u8(const uint8_t *joint, const uint8_t *src, uint8_t *dst, int h, in
     int *ofs = (int *)malloc(sizeof(int) * maxk);
     for (int k = 0; k < maxk; k++)
         ofs[k] = di[k] * pw + dj[k];
+    const int var_fma = (g_rfo_variants & RFO_VAR_JBF_FMA) != 0;
+    if (g_rfo_variants & RFO_VAR_JBF_TRUE_DIVISION)
+        flags |= RFO_FLAG_TRUE_DIVISION;
 
 #ifdef _OPENMP
     if (threads <= 0)
@@ -202,9 +232,14 @@ int rfo_jbf_u8(const uint8_t *joint, const uint8_t *src, uint8_t *dst, int h, in
                 for (int c = 0; c < joint_cn; c++)
                     alpha += abs(j0[c] - (int)jt[c]);
                 float weight = sw[k] * lut[alpha];
-                for (int c = 0; c < src_cn; c++) {
-                    float prod = weight * (float)st[c]; /* separately rounded mul ... */
-                    sum[c] = sum[c] + prod;              /* ... then add (no FMA)      */
+                if (var_fma) {
+                    for (int c = 0; c < src_cn; c++)
+                        sum[c] = fmaf(weight, (float)st[c], sum[c]);
+                } else {
+                    for (int c = 0; c < src_cn; c++) {
+                        float prod = weight * (float)st[c]; /* separately rounded mul ... */
+                        sum[c] = sum[c] + prod;              /* ... then add (no FMA)      */
+                    }
                 }
                 wsum = wsum + weight;
             }
@@ -357,8 +392,13 @@ int rfo_jbf_f32(const float *joint, const float *src, float *dst, int h, int w, 
  * ksize-1 rows above the first output row; each output is (float)(s * scale).
  * src and dst may alias.
  */
+static void rfo_box_mean_float_sums(const float *src, float *dst, int h, int w, int r);
 static void rfo_box_mean(const float *src, float *dst, int h, int w, int r)
 {
+    if (g_rfo_variants & RFO_VAR_GF_FLOAT_BOXSUM) {
+        rfo_box_mean_float_sums(src, dst, h, w, r);
+        return;
+    }
     int ks = 2 * r + 1;
     double scale = 1.0 / ((double)ks * (double)ks);
     double *rows = (double *)malloc(sizeof(double) * (size_t)h * w);
@@ -404,7 +444,51 @@ static void rfo_box_mean(const float *src, float *dst, int h, int w, int r)
     free(rows);
 }
 
-/* edgeaware_filters_common.cpp element-wise helpers */
+/* RFO_VAR_GF_FLOAT_BOXSUM: the same two running sums held in float (RowSum<float,float>,
+ * ColumnSum<float,float>: out = s * (float)scale) */
+static void rfo_box_mean_float_sums(const float *src, float *dst, int h, int w, int r)
+{
+    int ks = 2 * r + 1;
+    float scale = (float)(1.0 / ((double)ks * (double)ks));
+    float *rows = (float *)malloc(sizeof(float) * (size_t)h * w);
+    int ew = w + ks - 1;
+    float *ext = (float *)malloc(sizeof(float) * ew);
+    for (int y = 0; y < h; y++) {
+        const float *S0 = src + (size_t)y * w;
+        float *D = rows + (size_t)y * w;
+        for (int x = 0; x < ew; x++)
+            ext[x] = S0[rfo_border_interpolate(x - r, w, RFO_BORDER_REFLECT)];
+        float s = 0;
+        for (int i = 0; i < ks; i++)
+            s += ext[i];
+        D[0] = s;
+        for (int i = 0; i < w - 1; i++) {
+            s += ext[i + ks] - ext[i];
+            D[i + 1] = s;
+        }
+    }
+    float *SUM = (float *)calloc(w, sizeof(float));
+    for (int yy = -r; yy < r; yy++) {
+        const float *Sp = rows + (size_t)rfo_border_interpolate(yy, h, RFO_BORDER_REFLECT) * w;
+        for (int i = 0; i < w; i++)
+            SUM[i] += Sp[i];
+    }
+    for (int y = 0; y < h; y++) {
+        const float *Sp = rows + (size_t)rfo_border_interpolate(y + r, h, RFO_BORDER_REFLECT) * w;
+        const float *Sm = rows + (size_t)rfo_border_interpolate(y - r, h, RFO_BORDER_REFLECT) * w;
+        float *D = dst + (size_t)y * w;
+        for (int i = 0; i < w; i++) {
+            float s0 = SUM[i] + Sp[i];
+            D[i] = s0 * scale;
+            SUM[i] = s0 - Sm[i];
+        }
+    }
+    free(SUM);
+    free(ext);
+    free(rows);
+}
+
+/* edgeaware_filters_common.cpp element-wise helpers (RFO_VAR_GF_FMA: contracted forms) */
 static void ew_mul(float *d, const float *a, const float *b, size_t n)
 {
     for (size_t i = 0; i < n; i++)
@@ -412,6 +496,11 @@ static void ew_mul(float *d, const float *a, const float *b, size_t n)
 }
 static void ew_sub_mul(float *d, const float *a, const float *b, size_t n)
 {
+    if (g_rfo_variants & RFO_VAR_GF_FMA) {
+        for (size_t i = 0; i < n; i++)
+            d[i] = fmaf(-a[i], b[i], d[i]);
+        return;
+    }
     for (size_t i = 0; i < n; i++) {
         float p = a[i] * b[i];
         d[i] = d[i] - p;
@@ -419,6 +508,11 @@ static void ew_sub_mul(float *d, const float *a, const float *b, size_t n)
 }
 static void ew_add_mul(float *d, const float *a, const float *b, size_t n)
 {
+    if (g_rfo_variants & RFO_VAR_GF_FMA) {
+        for (size_t i = 0; i < n; i++)
+            d[i] = fmaf(a[i], b[i], d[i]);
+        return;
+    }
     for (size_t i = 0; i < n; i++) {
         float p = a[i] * b[i];
         d[i] = d[i] + p;
@@ -426,6 +520,11 @@ static void ew_add_mul(float *d, const float *a, const float *b, size_t n)
 }
 static void ew_sub_mad(float *d, const float *a, const float *b, float c0, size_t n)
 {
+    if (g_rfo_variants & RFO_VAR_GF_FMA) {
+        for (size_t i = 0; i < n; i++)
+            d[i] = d[i] - fmaf(a[i], b[i], c0);
+        return;
+    }
     for (size_t i = 0; i < n; i++) {
         float p = a[i] * b[i];
         float q = p + c0;
@@ -490,10 +589,15 @@ static int gf_core(const float *guide_f, const float *src_f, uint8_t *dst, float
     for (int c1 = 0; c1 < 3; c1++)
         for (int c2 = c1; c2 < 3; c2++) {
             float *cv = cov[sym_idx(c1, c2)];
-            if (c1 != c2)
+            if (c1 != c2) {
                 ew_sub_mul(cv, mI[c1], mI[c2], n);
-            else
+            } else if (g_rfo_variants & RFO_VAR_GF_DIAG_ADD_EPS) {
+                ew_sub_mul(cv, mI[c1], mI[c2], n);
+                for (size_t i = 0; i < n; i++)
+                    cv[i] = cv[i] + diag;
+            } else {
                 ew_sub_mad(cv, mI[c1], mI[c2], -diag, n);
+            }
         }
     /* ComputeCovGuideInv_ParBody, 3-channel branch */
     float *det = (float *)malloc(sizeof(float) * n);
@@ -680,6 +784,9 @@ int rfo_cnn_reflectance_u8(const uint8_t *bgr, float *r, uint8_t *r_u8, int h, i
     }
     const float *wf = q, *bf = q + 160;
     size_t n = (size_t)h * w;
+    const int no_fma = (g_rfo_variants & RFO_VAR_CNN_GEMM_NO_FMA) != 0;
+    const int sig_tanh = (g_rfo_variants & RFO_VAR_CNN_SIGMOID_TANH) != 0;
+#define RFO_MAC(wv, xv, acc) (no_fma ? (acc) + (wv) * (xv) : fmaf((wv), (xv), (acc)))
 #ifdef _OPENMP
     if (threads <= 0)
         threads = omp_get_max_threads();
@@ -692,7 +799,7 @@ int rfo_cnn_reflectance_u8(const uint8_t *bgr, float *r, uint8_t *r_u8, int h, i
         for (int o = 0; o < 32; o++) {
             float acc = 0.0f;
             for (int k = 0; k < 3; k++)
-                acc = fmaf(W0[o * 3 + k], x[k], acc);
+                acc = RFO_MAC(W0[o * 3 + k], x[k], acc);
             acc = acc + b0[o];
             hcur[o] = acc > 0.0f ? acc : 0.0f;
             cat[o] = hcur[o];
@@ -701,7 +808,7 @@ int rfo_cnn_reflectance_u8(const uint8_t *bgr, float *r, uint8_t *r_u8, int h, i
             for (int o = 0; o < 32; o++) {
                 float acc = 0.0f;
                 for (int k = 0; k < 32; k++)
-                    acc = fmaf(Wl[l][o * 32 + k], hcur[k], acc);
+                    acc = RFO_MAC(Wl[l][o * 32 + k], hcur[k], acc);
                 acc = acc + bl[l][o];
                 hnext[o] = acc > 0.0f ? acc : 0.0f;
             }
@@ -710,11 +817,13 @@ int rfo_cnn_reflectance_u8(const uint8_t *bgr, float *r, uint8_t *r_u8, int h, i
         }
         float z = 0.0f;
         for (int k = 0; k < 160; k++)
-            z = fmaf(wf[k], cat[k], z);
+            z = RFO_MAC(wf[k], cat[k], z);
         z = z + bf[0];
         /* expf(-z) modelled as the correctly rounded float of exp in double */
         float e = (float)exp((double)(-z));
         float rv = (float)(1.0 / (1.0 + (double)e));
+        if (sig_tanh) /* 0.5 * tanh(0.5 * x) + 0.5 in float, tanhf modelled as rounded double tanh */
+            rv = 0.5f * (float)tanh((double)(0.5f * z)) + 0.5f;
         if (r)
             r[i] = rv;
         if (r_u8) {
@@ -722,5 +831,6 @@ int rfo_cnn_reflectance_u8(const uint8_t *bgr, float *r, uint8_t *r_u8, int h, i
             r_u8[i] = (uint8_t)s; /* astype(uint8): truncation toward zero */
         }
     }
+#undef RFO_MAC
     return 0;
 }

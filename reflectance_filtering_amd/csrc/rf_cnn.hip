@@ -500,9 +500,11 @@ __global__ __launch_bounds__(kCnnThreads) void cnn_reflectance_regs_kernel(
 // the last call), so calls on different streams never share a buffer and calls on one stream are
 // ordered.  The table is bounded (kMaxSlots): when it is full the least recently used slot whose
 // stream has drained is recycled (a stream that no longer exists counts as drained; if every slot
-// is busy the oldest one's stream is waited for).  Nothing is allocated or recycled while the
-// caller's stream is being captured: a capture needs either a slot made by an earlier call on
-// that stream or the stateless pair rf_cnn_pack_weights + rf_cnn_reflectance_packed_u8.
+// is busy the oldest one's stream is waited for).  A slot is handed out with the table's mutex
+// HELD and the caller enqueues its two kernels before releasing it, so no other thread can see
+// the slot's stream as drained in between and take the buffer.  A stream that is being captured
+// is refused: a graph would bake a slot's pointer in and replay it after the slot has gone to
+// another stream - graphs use the stateless pair rf_cnn_pack_weights + rf_cnn_reflectance_packed_u8.
 struct PackedSlot {
     int device;
     hipStream_t stream;
@@ -514,25 +516,26 @@ std::mutex g_cnn_mu;
 std::vector<PackedSlot> g_packed;
 unsigned long long g_tick = 0;
 
-int packed_buffer(hipStream_t stream, float **out)
+int packed_buffer(hipStream_t stream, float **out, std::unique_lock<std::mutex> &lock)
 {
     int dev = 0;
     RF_HIP_CHECK(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lock(g_cnn_mu);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess)
+        (void)hipGetLastError();
+    if (cap != hipStreamCaptureStatusNone)
+        return fail(RF_E_UNSUPPORTED,
+                    "rf_cnn_reflectance_u8: the stream is being captured; this entry point keeps its "
+                    "packed weights in a per-stream slot of the library that a later call may hand "
+                    "to another stream - capture rf_cnn_reflectance_packed_u8 on weights packed "
+                    "beforehand with rf_cnn_pack_weights");
+    lock = std::unique_lock<std::mutex>(g_cnn_mu);  // held until the caller has enqueued its work
     for (PackedSlot &s : g_packed)
         if (s.device == dev && s.stream == stream) {
             s.used = ++g_tick;
             *out = s.buf;
             return RF_OK;
         }
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(stream, &cap) != hipSuccess)
-        (void)hipGetLastError();
-    if (cap != hipStreamCaptureStatusNone)
-        return fail(RF_E_UNSUPPORTED,
-                    "rf_cnn_reflectance_u8: first call on a stream that is being captured (it would "
-                    "allocate); call it once on this stream before the capture, or capture "
-                    "rf_cnn_reflectance_packed_u8 on weights packed beforehand");
     if (g_packed.size() >= kMaxSlots) {
         // recycle: least recently used slot whose stream has nothing pending
         size_t pick = g_packed.size(), oldest = 0;
@@ -663,7 +666,8 @@ extern "C" int rf_cnn_reflectance_u8(const uint8_t *bgr, float *r_out, uint8_t *
         return rc;
     hipStream_t stream = (hipStream_t)stream_;
     float *packed = nullptr;
-    rc = packed_buffer(stream, &packed);
+    std::unique_lock<std::mutex> slot_lock;  // released when both kernels are enqueued
+    rc = packed_buffer(stream, &packed, slot_lock);
     if (rc != RF_OK)
         return rc;
     // (the packed copy is rebuilt on the caller's stream every call: the weights may have changed)

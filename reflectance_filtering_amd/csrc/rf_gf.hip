@@ -749,6 +749,22 @@ int gf_f32_chunk(const float *guide, const float *src, float *dst, int m, int h,
     return RF_OK;
 }
 
+// uint8 <-> float images for radii beyond the 8-bit kernels' range (rf_gf_u8 -> float kernels)
+__global__ __launch_bounds__(256) void gf_u8_to_f32_kernel(const uint8_t *__restrict__ in,
+                                                           float *__restrict__ out, size_t count)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+         i += (size_t)gridDim.x * blockDim.x)
+        out[i] = (float)in[i];
+}
+__global__ __launch_bounds__(256) void gf_f32_to_u8_kernel(const float *__restrict__ in,
+                                                           uint8_t *__restrict__ out, size_t count)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+         i += (size_t)gridDim.x * blockDim.x)
+        out[i] = saturate_u8(in[i]);  // convertTo(CV_8U): round half to even, clamp, NaN -> 0
+}
+
 }  // namespace
 
 // Side streams for the second half of a batch, one per CALLER stream (so two callers never meet
@@ -756,12 +772,15 @@ int gf_f32_chunk(const float *guide, const float *src, float *dst, int m, int h,
 // stream into that capture).  The table is bounded: when it is full the least recently used entry
 // whose side stream is idle is destroyed and replaced; if none is idle, or the caller's stream
 // belongs to another device than the current one, the call runs on the caller's stream alone
-// (nullptr).  rf_shutdown() destroys them all.
+// (nullptr).  An entry is held (busy) from gf_side_stream until the call that got it has enqueued
+// everything (gf_side_release): an idle-looking stream is not taken from under a call that is
+// about to use it.  rf_shutdown() destroys them all.
 namespace {
 struct SideStream {
     hipStream_t caller, side;
     int device;
     unsigned long long used;
+    int busy;  // calls that hold this entry and may not have enqueued their work yet: never recycled
 };
 constexpr size_t kMaxSideStreams = 16;
 std::mutex g_side_mu;
@@ -787,13 +806,14 @@ hipStream_t gf_side_stream(hipStream_t caller)
     for (size_t i = 0; i < g_side_n; i++)
         if (g_side[i].caller == caller && g_side[i].device == dev) {
             g_side[i].used = ++g_side_tick;
+            g_side[i].busy++;
             return g_side[i].side;
         }
     size_t slot = g_side_n;
     if (g_side_n == kMaxSideStreams) {
         slot = kMaxSideStreams;
         for (size_t i = 0; i < g_side_n; i++) {
-            if (slot != kMaxSideStreams && g_side[i].used > g_side[slot].used)
+            if (g_side[i].busy > 0 || (slot != kMaxSideStreams && g_side[i].used > g_side[slot].used))
                 continue;
             hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
             if (hipStreamIsCapturing(g_side[i].side, &cap) != hipSuccess ||
@@ -816,10 +836,22 @@ hipStream_t gf_side_stream(hipStream_t caller)
         }
         return nullptr;
     }
-    g_side[slot] = {caller, st, dev, ++g_side_tick};
+    g_side[slot] = {caller, st, dev, ++g_side_tick, 1};
     if (slot == g_side_n)
         g_side_n++;
     return st;
+}
+
+void gf_side_release(hipStream_t side)
+{
+    if (side == nullptr)
+        return;
+    std::lock_guard<std::mutex> lock(g_side_mu);
+    for (size_t i = 0; i < g_side_n; i++)
+        if (g_side[i].side == side && g_side[i].busy > 0) {
+            g_side[i].busy--;
+            return;
+        }
 }
 
 void gf_shutdown()
@@ -877,6 +909,14 @@ size_t gf_per_img_row_walk(size_t npx, int np, int nb, int h)
     return (size_t)np * (npx * sizeof(float) + (size_t)nb * h * sizeof(double));
 }
 constexpr size_t kGfSyncBytes = 256;
+// radii above this run the float kernels (uint32 window sums: (2r+1)^2 * 255^2 < 2^32; strip width)
+constexpr int kGfMaxRadiusU8 = 120;
+// ... on float copies of guide, src and result + the float kernels' own planes and row sums
+size_t gf_per_img_via_f32(size_t npx, int src_cn)
+{
+    return npx * ((3 + 2 * (size_t)src_cn) * sizeof(float) +
+                  (9 + 4 * (size_t)src_cn) * (sizeof(float) + sizeof(double)));
+}
 size_t gf_chain_xst_bytes(int src_cn, int nb, int h, int radius)
 {
     return (size_t)src_cn * nb * gf_chain_nsub(h, radius) * 64 * 16;
@@ -895,6 +935,8 @@ extern "C" size_t rf_gf_workspace_bytes(int n, int h, int w, int guide_cn, int s
         return 0;
     // the larger of the forms a call may take (small images: the chained form's fixed part)
     size_t per_img = rf::gf_per_img_two_kernel((size_t)h * w, 4 * src_cn);
+    if (radius > rf::kGfMaxRadiusU8)  // float kernels on float copies of the images (rf_gf_u8)
+        per_img = rf::gf_per_img_via_f32((size_t)h * w, src_cn);
     if (radius >= 1 && radius <= rf::kGfFusedMaxRadius)
         per_img = std::max(per_img, rf::gf_per_img_chained((size_t)h * w, 4 * src_cn,
                                                            rf::ceil_div(w, rf::kSB), h, radius));
@@ -910,6 +952,10 @@ extern "C" size_t rf_gf_workspace_bytes(int n, int h, int w, int guide_cn, int s
         imgs = 1;
     return rf::gf_header_bytes(n) + imgs * per_img;
 }
+
+extern "C" int rf_gf_f32(const float *guide, const float *src, float *dst, int n, int h, int w,
+                         int guide_cn, int src_cn, int radius, double eps, int iterations,
+                         void *workspace, size_t workspace_bytes, void *stream_);
 
 extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, int n, int h,
                         int w, int guide_cn, int src_cn, int radius, double eps, int iterations,
@@ -927,9 +973,8 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
         return fail(RF_E_UNSUPPORTED, "rf_gf_u8: guide must have 3 channels (got %d)", guide_cn);
     if (src_cn != 1 && src_cn != 3)
         return fail(RF_E_UNSUPPORTED, "rf_gf_u8: src channels must be 1 or 3 (got %d)", src_cn);
-    // uint32 window sums: (2r+1)^2 * 255^2 must stay below 2^32; strip width must hold the halo
-    if (radius < 0 || radius > 120)
-        return fail(RF_E_UNSUPPORTED, "rf_gf_u8: radius %d outside 0..120", radius);
+    if (radius < 0 || radius > 4096)
+        return fail(RF_E_UNSUPPORTED, "rf_gf_u8: radius %d outside 0..4096", radius);
     {
         const size_t px = (size_t)n * h * w;
         if (ranges_overlap(dst, px * src_cn, guide, px * 3))
@@ -944,6 +989,44 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
     const int nb = ceil_div(w, kSB);
     const size_t header = gf_header_bytes(n);
     hipStream_t stream = (hipStream_t)stream_;
+    if (radius > kGfMaxRadiusU8) {
+        // Beyond the 8-bit kernels' range (int(sigma_spatial) is a free parameter of the reference's
+        // tool, /root/reference/filter_reflectance.py:67-70,118): the float kernels of rf_gf_f32 on
+        // float copies of the images, every pass rounded to uint8 like convertTo(CV_8U).  On 8-bit
+        // data the float path's double window sums are the same exact integers the 8-bit stage 1
+        // forms, so the bytes are what the 8-bit kernels would give (tests: both against the oracle).
+        const size_t per_img_f = gf_per_img_via_f32(npx, src_cn);
+        if (workspace_bytes < header + per_img_f)
+            return fail(RF_E_WORKSPACE, "rf_gf_u8: workspace %zu B < %zu B needed for one image at "
+                        "radius %d", workspace_bytes, header + per_img_f, radius);
+        const size_t f32_ws = npx * (9 + 4 * (size_t)src_cn) * (sizeof(float) + sizeof(double));
+        int chunk = (int)std::min<size_t>((size_t)n, (workspace_bytes - header) / per_img_f);
+        char *ws0 = static_cast<char *>(workspace) + header;
+        for (int i0 = 0; i0 < n; i0 += chunk) {
+            const int m = std::min(chunk, n - i0);
+            float *gF = reinterpret_cast<float *>(ws0);
+            float *sF = gF + (size_t)m * npx * 3;
+            float *dF = sF + (size_t)m * npx * src_cn;
+            void *fw = dF + (size_t)m * npx * src_cn;
+            const size_t cg = (size_t)m * npx * 3, cs = (size_t)m * npx * src_cn;
+            const unsigned bg = (unsigned)std::min<size_t>((cg + 255) / 256, 65535);
+            const unsigned bs = (unsigned)std::min<size_t>((cs + 255) / 256, 65535);
+            hipLaunchKernelGGL(gf_u8_to_f32_kernel, dim3(bg), dim3(256), 0, stream,
+                               guide + (size_t)i0 * npx * 3, gF, cg);
+            uint8_t *d0 = dst + (size_t)i0 * npx * src_cn;
+            for (int it = 0; it < iterations; it++) {
+                const uint8_t *s0 = it == 0 ? src + (size_t)i0 * npx * src_cn : d0;
+                hipLaunchKernelGGL(gf_u8_to_f32_kernel, dim3(bs), dim3(256), 0, stream, s0, sF, cs);
+                const int rc = rf_gf_f32(gF, sF, dF, m, h, w, 3, src_cn, radius, eps, 1, fw,
+                                         (size_t)m * f32_ws, stream_);
+                if (rc != RF_OK)
+                    return rc;
+                hipLaunchKernelGGL(gf_f32_to_u8_kernel, dim3(bs), dim3(256), 0, stream, dF, d0, cs);
+            }
+        }
+        RF_HIP_CHECK(hipGetLastError());
+        return RF_OK;
+    }
     // Stage 2 (box means of alpha/beta), three forms with identical bytes:
     //   row walk + column walk (default for the instantiated radii 1..96)
     //   chained column walk (debug option "gf_chained": no row-walk kernel, every block takes its row
@@ -1135,6 +1218,10 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
     const int fork_from = debug_get(kDbgGfForceTwoStreams) ? 2 : 8;
     if (fused && chunk >= fork_from && !debug_get(kDbgGfOneStream))
         side = gf_side_stream(stream);
+    struct SideHold {  // the entry stays ours until every launch of this call is enqueued
+        hipStream_t s;
+        ~SideHold() { gf_side_release(s); }
+    } side_hold{side};
     for (int i0 = 0; i0 < n; i0 += chunk) {
         const int m = std::min(chunk, n - i0);
         if (side == nullptr || m < fork_from) {

@@ -44,8 +44,10 @@ def to_pixels(comparisons, height, width):
     back in the array's own dtype; the judgement and weight columns are untouched
     (contract: whdr_layer.py:239-250)."""
     px = np.array(comparisons, copy=True)
-    size = np.array([width, height, width, height])
-    px[:, :4] = np.trunc(px[:, :4] * size)
+    # the products are formed in the array's own dtype (float32 blobs stay float32: for a
+    # coordinate k / width the float32 product rounds to k, the float64 one truncates to k - 1)
+    for cols, size in (([0, 2], int(width)), ([1, 3], int(height))):
+        px[:, cols] = np.trunc(px[:, cols] * size)
     return px
 
 

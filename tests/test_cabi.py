@@ -207,7 +207,10 @@ def test_argument_validation_needs_no_gpu(built):
     assert lib.rf_debug_option(b"gf_two_kernel", 0) == 1
     assert lib.rf_gf_u8(p, q, o, 1, 4, 4, 1, 3, 2, 1.0, 1, p, 1 << 20, None) == _ffi.RF_E_UNSUPPORTED
     assert lib.rf_gf_u8(p, q, o, 1, 4, 4, 3, 3, 2, 1.0, 0, p, 1 << 20, None) == _ffi.RF_E_BADARG
-    assert lib.rf_gf_u8(p, q, o, 1, 4, 4, 3, 3, 500, 1.0, 1, p, 1 << 20, None) == _ffi.RF_E_UNSUPPORTED
+    assert lib.rf_gf_u8(p, q, o, 1, 4, 4, 3, 3, 5000, 1.0, 1, p, 1 << 20, None) == _ffi.RF_E_UNSUPPORTED
+    # radii above 120 run the float kernels on float copies of the images: a larger workspace
+    assert lib.rf_gf_u8(p, q, o, 1, 64, 64, 3, 3, 500, 1.0, 1, p, 1 << 16, None) == _ffi.RF_E_WORKSPACE
+    assert lib.rf_gf_workspace_bytes(1, 64, 64, 3, 3, 500) > lib.rf_gf_workspace_bytes(1, 64, 64, 3, 3, 45)
     assert lib.rf_gf_u8(p, q, o, 1, 64, 64, 3, 3, 2, 1.0, 1, p, 16, None) == _ffi.RF_E_WORKSPACE
     assert lib.rf_cnn_reflectance_u8(p, None, None, 1, 4, 4, p, p, None) == _ffi.RF_E_BADARG
     assert lib.rf_cnn_reflectance_packed_u8(p, None, None, 1, 4, 4, p, p, None) == _ffi.RF_E_BADARG

@@ -708,17 +708,15 @@ def test_captured_call_with_cnn_and_raw_entry_point_rules(env):
     side = torch.cuda.Stream()
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph, stream=side):
-        rc_first = raw_call(side.cuda_stream)       # no slot for this stream yet: refused, not captured
+        rc_first = raw_call(side.cuda_stream)       # a capturing stream is refused, nothing captured
     assert rc_first == rf._ffi.RF_E_UNSUPPORTED and b"captured" in lib.rf_last_error()
     assert raw_call(side.cuda_stream) == rf._ffi.RF_OK     # eager call makes the slot
     torch.cuda.synchronize()
+    assert torch.equal(r, want_r)
     graph2 = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph2, stream=side):
-        assert raw_call(side.cuda_stream) == rf._ffi.RF_OK
-    r.zero_()
-    graph2.replay()
-    torch.cuda.synchronize()
-    assert torch.equal(r, want_r)
+        # ... and still refused with a slot: a graph would bake in a pointer the library recycles
+        assert raw_call(side.cuda_stream) == rf._ffi.RF_E_UNSUPPORTED
     streams = [torch.cuda.Stream() for _ in range(40)]      # more streams than slots
     for st in streams:
         assert raw_call(st.cuda_stream) == rf._ffi.RF_OK
@@ -887,6 +885,43 @@ def test_gf_fused_stage2_any_radius(env, radius):
         with rf._ffi.debug_options(gf_two_kernel=1):
             b = rf.ops.guided_filter_u8(gg, ss, radius, eps, iterations=3)
         assert torch.equal(a, b), (radius, hh, ww)
+
+
+def test_gf_radius_beyond_the_8bit_kernels(env):
+    """int(sigma_spatial) is a free parameter of the reference's tool
+    (/root/reference/filter_reflectance.py:67-70,118): radii above 120 run the float kernels inside
+    rf_gf_u8 and round every pass to uint8 - the oracle's bytes, through apply_filter, the batch
+    operator (two passes, grey and colour and 1-channel src) and with a workspace for one image."""
+    from tests import synth
+    rf, co, torch = env
+    h, w = 200, 300
+    joint = synth.flat_guide_u8(h, w, seed=5, cells=12)
+    image = synth.reflectance_like_u8(h, w, seed=6)
+    got = rf.filter_reflectance.apply_filter("guided", image, joint, sigma_color=3.0,
+                                             sigma_spatial=150)
+    assert got.dtype == np.uint8 and got.shape == image.shape
+    assert np.array_equal(got, co.guided_filter(joint, image, 150, 3.0))
+    colour = synth.scene_u8(h, w, seed=7)
+    g = torch.from_numpy(np.stack([joint, joint])).cuda()
+    s = torch.from_numpy(np.stack([colour, image])).cuda()
+    for radius, eps in ((121, 7.0), (260, 3.0)):
+        got2 = rf.ops.guided_filter_u8(g, s, radius, eps, iterations=2).cpu().numpy()
+        for i, src in enumerate((colour, image)):
+            want = co.guided_filter(joint, co.guided_filter(joint, src, radius, eps), radius, eps)
+            assert np.array_equal(got2[i], want), (radius, i)
+    one = torch.from_numpy(image[None, :, :, :1].copy()).cuda()
+    lib = rf._ffi.load_library()
+    need1 = lib.rf_gf_workspace_bytes(1, h, w, 3, 1, 121)
+    ws = torch.empty(need1, dtype=torch.uint8, device="cuda")
+    three = one.expand(3, -1, -1, -1).contiguous()
+    got3 = rf.ops.guided_filter_u8(g[:1].expand(3, -1, -1, -1).contiguous(), three, 121, 7.0,
+                                   workspace=ws).cpu().numpy()
+    want1 = co.guided_filter(joint, image[:, :, :1].copy(), 121, 7.0).reshape(got3[0].shape)
+    for i in range(3):
+        assert np.array_equal(got3[i], want1)
+    # radius 120 (8-bit kernels) and 121 (float kernels) agree with the oracle on either side
+    a = rf.ops.guided_filter_u8(g[:1], s[1:], 120, 3.0).cpu().numpy()[0]
+    assert np.array_equal(a, co.guided_filter(joint, image, 120, 3.0))
 
 
 @pytest.mark.parametrize("radius,eps", [(45, 3.0), (52, 7.0)])

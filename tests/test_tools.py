@@ -59,3 +59,37 @@ def test_t2_report_with_a_stand_in_opencv(tmp_path, monkeypatch):
     assert len(off) == 1 and off[0]["oracle_vs_opencv"]["max_abs"] == 1
     assert doc["worst_max_abs"] == 1 and "differs" in doc["verdict"]
     assert all(c["frozen_vector_vs_opencv"]["max_abs"] <= 1 for c in doc["cases"])
+
+
+def test_t2_report_identifies_a_non_default_variant(tmp_path, monkeypatch):
+    """A stand-in `cv2` whose filters make two of the choices the oracle recalled differently (true
+    division in the joint bilateral; FMA-contracted helpers and `+ eps` on the diagonal in the
+    guided filter): the report's variant search names exactly those switches."""
+    from oracle import c_oracle as co
+
+    def jbf(joint, src, d, sc, ss):
+        with co.variants("jbf_true_division"):
+            return co.joint_bilateral_filter(joint, src, d, sc, ss)
+
+    def gf(guide, src, radius, eps):
+        with co.variants("gf_fma", "gf_diag_add_eps"):
+            return co.guided_filter(guide, src, radius, eps)
+
+    fake = types.ModuleType("cv2")
+    fake.__version__ = "0.0-variant"
+    fake.error = RuntimeError
+    fake.getBuildInformation = lambda: "stand-in build with other choices"
+    fake.getNumThreads = lambda: 1
+    fake.ximgproc = types.SimpleNamespace(jointBilateralFilter=jbf, guidedFilter=gf)
+    monkeypatch.setitem(sys.modules, "cv2", fake)
+    out = tmp_path / "t2.json"
+    assert _load("t2_report").main(["--out", str(out), "--no-gpu"]) == 0
+    assert co.lib().rfo_get_variants() == 0                 # the search leaves the default behind
+    vs = json.loads(out.read_text())["variant_search"]
+    assert vs["gf"]["identified"] == [["gf_diag_add_eps", "gf_fma"]]
+    assert not vs["gf"]["default_is_exact"] and "flip" in vs["gf"]["reading"]
+    # the 8-bit joint bilateral hides most last-ulp choices behind its rounding: the true combination
+    # is among the identified ones, the default is not, and every identified one divides truly
+    assert ["jbf_true_division"] in vs["jbf"]["identified"]
+    assert not vs["jbf"]["default_is_exact"]
+    assert all("jbf_true_division" in c for c in vs["jbf"]["identified"])

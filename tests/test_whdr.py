@@ -112,3 +112,31 @@ def test_device_batch_matches_reference_and_host(built):
     assert g3.shape == (9,)
     with pytest.raises(IndexError):
         W.whdr_batch(torch.zeros((1, 1, 4, 4), device="cuda"), [np.array([[4, 0, 1, 1, 1, 1.0]])])
+
+
+def test_to_pixels_keeps_float32_products():
+    """Coordinates of a float32 blob are multiplied in float32 (whdr_layer.py:248-249 multiplies
+    the array by a Python int): k / w as float32 times w rounds back to k, where the float64
+    product of the same float32 value is just below k and truncates to k - 1."""
+    h, w = 333, 500
+    ks = np.arange(w, dtype=np.float32)
+    js = np.arange(h, dtype=np.float32)
+    n = max(h, w)
+    comp = np.zeros((n, 6), dtype=np.float32)
+    comp[:, 0] = np.resize(ks / np.float32(w), n)
+    comp[:, 2] = np.resize(ks[::-1] / np.float32(w), n)
+    comp[:, 1] = np.resize(js / np.float32(h), n)
+    comp[:, 3] = np.resize(js[::-1] / np.float32(h), n)
+    px = W.to_pixels(comp, h, w)
+    assert px.dtype == np.float32
+    want = comp.copy()                       # the reference's two statements, spelled out
+    want[:, [0, 2]] = (want[:, [0, 2]] * w).astype(int)
+    want[:, [1, 3]] = (want[:, [1, 3]] * h).astype(int)
+    assert np.array_equal(px, want)
+    wrong = np.trunc(comp[:, :4].astype(np.float64) * np.array([w, h, w, h]))
+    assert (wrong != px[:, :4]).any()        # the float64 product does land elsewhere
+    # float64 judgements (load_judgements) are untouched by the change
+    c64 = comp.astype(np.float64)
+    p64 = W.to_pixels(c64, h, w)
+    assert p64.dtype == np.float64
+    assert np.array_equal(p64[:, :4], np.trunc(c64[:, :4] * np.array([w, h, w, h])))

@@ -42,7 +42,7 @@ def main():
     # C5: 3x guided filter c=3 s=45 at 3840x2160, piecewise-constant guidance
     n, h, w = args.gf_batch, 2160, 3840
     scene, grey = bench.synth_batch(torch, n, h, w, 5000, dev)
-    flat = (scene // 32) * 32 + 16  # posterised scene = piecewise-constant "flat" guidance
+    flat = bench.flat_guide(scene)  # seeded Voronoi cells of flat colour
     dst = torch.empty_like(grey)
     # grey src (the CNN map the reference filters; three equal channels -> one-channel path)
     # and a colour src (all three channels computed)
@@ -53,6 +53,37 @@ def main():
             out["gf_4k_x%d%s" % (iters, tag)] = {"ms": ms, "batch": n,
                                                  "mp_per_s": n * h * w / 1e6 / (ms * 1e-3)}
     del scene, grey, flat, dst
+    torch.cuda.empty_cache()
+
+    # Joint bilateral beside the headline parameter set (c20 s22 -> radius 33, 3,409 taps, the 144-texel
+    # row pitch): the reference's other published set c15 s28 with a flat joint and a colour src
+    # (/root/reference/README.md:64: radius 42, 5,525 taps, the 176-texel pitch whose colour tiles run
+    # as 32/16/8-row passes of 8-byte texels), the same with the grey map as src, the headline radius
+    # with the same inputs, and a radius beyond the LDS tile (sigma_s 36 -> radius 54: generic kernel).
+    # taps/s next to MP/s, so that loops of different radii can be compared.
+    def taps_of(radius):
+        return sum(1 for i in range(-radius, radius + 1) for j in range(-radius, radius + 1)
+                   if (i * i + j * j) ** 0.5 <= radius)
+
+    nj, hj, wj = 32, 1080, 1920
+    scene, grey = bench.synth_batch(torch, nj, hj, wj, 5005, dev)
+    flatj = bench.flat_guide(scene)
+    colour_src = scene.roll(shifts=(37, 91), dims=(1, 2)).contiguous()
+    dstj = torch.empty_like(scene)
+    for tag, joint, src, sc, ss in (("jbf_c15s28_flat_colour", flatj, colour_src, 15.0, 28.0),
+                                    ("jbf_c15s28_flat_grey", flatj, grey, 15.0, 28.0),
+                                    ("jbf_c20s22_flat_colour", flatj, colour_src, 20.0, 22.0),
+                                    ("jbf_c20s22_flat_grey", flatj, grey, 20.0, 22.0),
+                                    ("jbf_c20s36_generic_colour", flatj[:4], colour_src[:4], 20.0, 36.0)):
+        radius = int(round(1.5 * ss))
+        nb_ = joint.shape[0]
+        d_ = dstj[:nb_]
+        ms = timed(torch, lambda: rf.ops.joint_bilateral_u8(joint, src, -1, sc, ss, out=d_), reps=2)
+        mp = nb_ * hj * wj / 1e6
+        out[tag] = {"ms": ms, "batch": nb_, "radius": radius, "taps_per_px": taps_of(radius),
+                    "mp_per_s": mp / (ms * 1e-3),
+                    "gtaps_per_s": mp * 1e6 * taps_of(radius) / (ms * 1e-3) / 1e9}
+    del scene, grey, flatj, colour_src, dstj
     torch.cuda.empty_cache()
 
     # CV_32F variants (no BASELINE config uses them): 1080p, [0,1] data
@@ -146,6 +177,8 @@ def main():
             hbm(entry, 36)                    # 12 + 12 in, 12 out (float pixels)
         elif key == "jbf_f32_1080p":
             hbm(entry, 36)
+        elif key.startswith("jbf_c"):
+            hbm(entry, 9)
         elif key == "colorize_iiw":
             hbm(entry, 11)                    # 3 + 4 in, 3 + 1 out
     print(json.dumps(out, indent=1))

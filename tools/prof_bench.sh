@@ -8,7 +8,7 @@ O=gpurun_out
 mkdir -p $O
 rm -rf $O/prof_stats $O/prof_fetch $O/prof_write $O/prof_calib $O/prof_sq $O/prof_grbm $O/prof_sq_colour $O/prof_grbm_colour
 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
-B="python3 bench.py --cpu-seconds 0 --no-extras"
+B="python3 bench.py --cpu-seconds 0 --no-extras --traffic off"   # never nest a profiler under a profiler
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -- $B --steps 5 --warmup 1 > $O/prof_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/prof_fetch -- $B --steps 2 --warmup 1 > $O/prof_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/prof_write -- $B --steps 2 --warmup 1 > $O/prof_write.log 2>&1
