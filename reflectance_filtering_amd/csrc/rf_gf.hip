@@ -234,11 +234,15 @@ __device__ inline void gf_pixel_algebra(const float *m, float eps_f, int eps_sma
 }
 
 // colour[img] != 0  <=>  some pixel of the 3-channel image has unequal channels.
-// grid: (blocks per image, images); colour[] zeroed beforehand.
+// grid: (blocks per image, images); colour[] zeroed beforehand.  compact (optional): [img][npx]
+// bytes that receive channel 0 of every pixel - for an image that turns out grey this IS the
+// image, one byte per pixel, and what the first pass's stage 1 then reads (see rf_gf_u8).
 __global__ __launch_bounds__(256) void gf_grey_probe_kernel(const uint8_t *__restrict__ src,
-                                                            int *__restrict__ colour, size_t npx)
+                                                            int *__restrict__ colour, size_t npx,
+                                                            uint8_t *__restrict__ compact)
 {
     const uint8_t *simg = src + (size_t)blockIdx.y * npx * 3;
+    uint8_t *cimg = compact ? compact + (size_t)blockIdx.y * npx : nullptr;
     const size_t nquads = npx / 4;  // 4 pixels = 12 bytes = 3 dwords (image base is 4-aligned
                                     // only when npx*3*img is; use byte-safe loads)
     bool diff = false;
@@ -253,10 +257,16 @@ __global__ __launch_bounds__(256) void gf_grey_probe_kernel(const uint8_t *__res
         const uint32_t p2 = (d1 >> 16) | ((d2 & 0xffu) << 16), p3 = d2 >> 8;
         diff |= p0 != (p0 & 0xffu) * 0x010101u || p1 != (p1 & 0xffu) * 0x010101u ||
                 p2 != (p2 & 0xffu) * 0x010101u || p3 != (p3 & 0xffu) * 0x010101u;
+        if (cimg != nullptr) {
+            const uint32_t c4 = (p0 & 0xffu) | ((p1 & 0xffu) << 8) | ((p2 & 0xffu) << 16) | (p3 << 24 & 0xff000000u);
+            __builtin_memcpy(cimg + q * 4, &c4, 4);
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x < (int)(npx - nquads * 4)) {
         const uint8_t *p = simg + (nquads * 4 + threadIdx.x) * 3;
         diff |= p[0] != p[1] || p[1] != p[2];
+        if (cimg != nullptr)
+            cimg[nquads * 4 + threadIdx.x] = p[0];
     }
     if (diff)
         colour[blockIdx.y] = 1;
@@ -1058,15 +1068,16 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
     const size_t gs_bytes = (npx * kGsFloats * sizeof(float) + 15) & ~(size_t)15;  // parts stay 16-byte aligned
     const bool keep_gs = iterations > 1 && debug_get(kDbgGfGuideCache) &&
                          workspace_bytes - header >= (fused ? per_img_fused : per_img) + gs_bytes;
-    // Iterated calls on 3-channel sources: an image whose channels are equal (the reference filters
-    // the CNN's grey map, /root/reference/README.md:66) passes from one pass to the next as ONE byte
-    // per pixel in the workspace instead of three in dst - the column walk writes a third of the
-    // bytes, the next pass's stage 1 (its one-byte-per-pixel instantiation) fetches 4 instead of 6
-    // bytes per pixel and row; the last pass writes dst.  Bytes identical (debug option
-    // "gf_no_compact" keeps the three-channel hand-off).
+    // 3-channel sources: an image whose channels are equal (the reference filters the CNN's grey map,
+    // /root/reference/README.md:66) is handled as ONE byte per pixel in the workspace: the grey
+    // probe, which reads every src byte anyway, leaves channel 0 there for the first pass's stage 1
+    // (its one-byte-per-pixel instantiation fetches 4 instead of 6 bytes per pixel and row), and the
+    // passes of an iterated call hand their result on the same way - the column walk writes a third
+    // of the bytes - until the last pass writes dst.  Bytes identical (debug option "gf_no_compact"
+    // keeps the three-channel reads and hand-offs).
     const size_t cmp_want = (npx + 15) & ~(size_t)15;
     const size_t cmp_bytes =
-        (fused && src_cn == 3 && iterations > 1 && !debug_get(kDbgGfNoCompact) &&
+        (fused && src_cn == 3 && !debug_get(kDbgGfNoCompact) &&
          workspace_bytes - header >= per_img_fused + (keep_gs ? gs_bytes : 0) + cmp_want)
             ? cmp_want
             : 0;
@@ -1090,13 +1101,8 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
     if (src_cn == 3) {
         colour_all = reinterpret_cast<int *>(workspace);
         RF_HIP_CHECK(hipMemsetAsync(colour_all, 0, sizeof(int) * (size_t)n, stream));
-        const int pb = (int)std::min<size_t>(1024, (npx / 4 + 255) / 256 + 1);
-        for (int i0 = 0; i0 < n; i0 += 65535) {
-            const int m = std::min(65535, n - i0);
-            hipLaunchKernelGGL(gf_grey_probe_kernel, dim3(pb, m), dim3(256), 0, stream,
-                               src + (size_t)i0 * npx * 3, colour_all + i0, npx);
-        }
     }
+    const int probe_blocks = (int)std::min<size_t>(1024, (npx / 4 + 255) / 256 + 1);
 
     // One part = m images starting at i0, their scratch at ws, every launch on st.
     auto run_part = [&](int i0, int m, int m_fill, char *ws, hipStream_t st) {
@@ -1124,6 +1130,11 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
                                  : nullptr;
         const uint8_t *g0 = guide + (size_t)i0 * npx * 3;
         uint8_t *d0 = dst + (size_t)i0 * npx * src_cn;
+        // the part's grey probe (flags zeroed by the caller's stream before the fork); with the
+        // one-byte hand-off it also leaves every image's channel 0 in cmp for the first pass
+        if (colour_all != nullptr)
+            hipLaunchKernelGGL(gf_grey_probe_kernel, dim3(probe_blocks, m), dim3(256), 0, st,
+                               src + (size_t)i0 * npx * 3, colour_all + i0, npx, cmp);
         // row segments: enough workgroups to fill 256 CUs, but segments no shorter than 2r+1.
         // (tools/gf_seg_sweep.py: a pass is flat within 3 % between 34 and 135 rows per segment at
         // 4K - the 2r warm-up rows of a segment are cheap - and slower above; a model that picks
@@ -1138,16 +1149,22 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
         // cost more) wants fewer and longer segments, but not whole images: 32 images 15.7 / 16.4 /
         // 17.0 ms at 540 / 270 / 135 rows (1,280 / 2,560 / 5,120 workgroups), 96 images 48.2 / 48.9 /
         // 50.7 ms at 540 / 270 / 1080 rows.
+        // (round 4, the shard is bound by bytes: every segment reads 2r warm-up rows, and three
+        //  segments of 720 rows per 4K image beat eight of 270 by 2.4 % - 68.8 against 70.5 ms per C5
+        //  step, 540 rows 69.1, 405 / 180 / 1080 rows 71.5 / 71.7 / 72.8 - so the segment COUNT is now the
+        //  smallest that still gives every place of the chip about one workgroup, not a power of two)
         auto pick_seg = [&](int strips_k, long long min_wgs, int cap) {
-            int seg = h;
-            while (((long long)strips_k * ceil_div(h, seg) * m_fill < min_wgs || seg > cap) &&
-                   seg > 2 * (2 * radius + 1) && seg > 32)
-                seg = (seg + 1) / 2;
+            const long long per_seg = std::max<long long>(1, (long long)strips_k * m_fill);
+            long long k = (min_wgs + per_seg - 1) / per_seg;          // segments per image
+            k = std::max<long long>(k, ceil_div(h, cap));
+            k = std::min<long long>(std::max<long long>(k, 1), h);
+            int seg = ceil_div(h, (int)k);
+            seg = std::max(seg, std::min(h, std::max(2 * (2 * radius + 1), 32)));  // two windows at least
             if (debug_get(kDbgGfSegRows) > 0)
                 seg = std::min(h, debug_get(kDbgGfSegRows));
             return seg;
         };
-        const int seg_rows1 = pick_seg(strips1, 1536, h);
+        const int seg_rows1 = pick_seg(strips1, 960, h);
         const int seg_rows3 = pick_seg(strips3, 1024, std::max(6 * (2 * radius + 1), 512));
         for (int it = 0; it < iterations; it++) {
             const uint8_t *s0 = (it == 0 ? src : (const uint8_t *)dst) + (size_t)i0 * npx * src_cn;
@@ -1157,7 +1174,7 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
         if (src_cn == 3) {                                                                         \
             hipLaunchKernelGGL((gf_stage1_kernel<3, 3, MODE>), ga3, dim3(stage1_threads(3)), 0, st, \
                                g0, s0, ab, h, w, radius, eps_f, eps_small, seg_rows3, colour, gs, 3); \
-            if (it > 0 && cmp != nullptr)                                                          \
+            if (cmp != nullptr)                                                                    \
                 hipLaunchKernelGGL((gf_stage1_kernel<1, 1, MODE>), ga1, dim3(stage1_threads(1)), 0, \
                                    st, g0, cmp, ab, h, w, radius, eps_f, eps_small, seg_rows1,      \
                                    colour, gs, 3);                                                 \

@@ -122,8 +122,15 @@ __global__ __launch_bounds__(256) void gf_rowstate_kernel(const float *__restric
             sx = border_interpolate(min(t0 + cc, total - 1) - PAD - R, w, RF_BORDER_REFLECT);
 #pragma unroll
         for (int k = 0; k < 4; k++)
-            buf[k] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(S4) +
-                                                       ((srow[k] + (uint32_t)sx) << 4));
+        {
+            // (non-temporal: the row walk reads every alpha/beta value exactly once; keeping them out
+            //  of the L2 leaves it to the column walk of the other half of the batch: C5 step 67.9 ->
+            //  67.0 ms.  The same hint on stage 1's alpha/beta STORES costs 35 %.)
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            const f32x4 t_ = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(
+                reinterpret_cast<const char *>(S4) + ((srow[k] + (uint32_t)sx) << 4)));
+            buf[k] = make_float4(t_.x, t_.y, t_.z, t_.w);
+        }
     };
     double s = 0.0;
     float fifo[F];

@@ -42,8 +42,11 @@ def test_c5_4k_three_guided_passes_against_oracle(env, src_kind):
         assert torch.equal(rf.ops.guided_filter_u8(guide, src, 45, 3.0, iterations=3), got)
     g_np = guide[0].cpu().numpy()
     cur = src[0].cpu().numpy()
-    # the guide really is piecewise constant: few distinct colours, long flat runs
-    assert len(np.unique(g_np.reshape(-1, 3), axis=0)) <= 512
+    # the guide really is piecewise constant (seeded Voronoi cells of one colour +-1 dither): at most
+    # 2,000 regions x 27 dither offsets, and nearly every pixel within the dither of its left neighbour
+    assert len(np.unique(g_np.reshape(-1, 3), axis=0)) <= 2000 * 27
+    step = np.abs(g_np[:, 1:].astype(np.int16) - g_np[:, :-1].astype(np.int16)).max(axis=2)
+    assert (step <= 2).mean() > 0.97
     for _ in range(3):
         cur = co.guided_filter(g_np, cur, 45, 3.0)
     assert np.array_equal(got[0].cpu().numpy(), cur)
