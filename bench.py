@@ -187,30 +187,37 @@ def flat_guide(scene, seed=9000):
     gw = max(1, int(round((regions * w / float(h)) ** 0.5)))
     gh = max(1, int(round(regions / float(gw))))
     gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
     out = torch.empty_like(scene)
-    py = torch.arange(h, device=dev, dtype=torch.float32)
-    px = torch.arange(w, device=dev, dtype=torch.float32)
+    py = torch.arange(h, device=dev, dtype=torch.float32)[None, :, None]
+    px = torch.arange(w, device=dev, dtype=torch.float32)[None, None, :]
     cy = (torch.arange(h, device=dev) * gh) // h
     cx = (torch.arange(w, device=dev) * gw) // w
-    for i in range(n):
-        gen.manual_seed(seed + i)
-        sy = (torch.arange(gh, device=dev)[:, None] + torch.rand((gh, gw), device=dev, generator=gen)) * (h / float(gh))
-        sx = (torch.arange(gw, device=dev)[None, :] + torch.rand((gh, gw), device=dev, generator=gen)) * (w / float(gw))
-        colour = scene[i][sy.long().clamp_(0, h - 1), sx.long().clamp_(0, w - 1)].reshape(-1, 3)
-        best = torch.full((h, w), float("inf"), device=dev)
-        lab = torch.zeros((h, w), dtype=torch.long, device=dev)
+    step = max(1, min(n, (64 << 20) // max(1, h * w)))          # images per pass: ~64 Mpx of temporaries
+    for i0 in range(0, n, step):
+        m = min(step, n - i0)
+        img_ix = torch.arange(m, device=dev)[:, None, None]
+        sy = (torch.arange(gh, device=dev)[None, :, None]
+              + torch.rand((m, gh, gw), device=dev, generator=gen)) * (h / float(gh))
+        sx = (torch.arange(gw, device=dev)[None, None, :]
+              + torch.rand((m, gh, gw), device=dev, generator=gen)) * (w / float(gw))
+        colour = scene[i0:i0 + m][img_ix, sy.long().clamp_(0, h - 1), sx.long().clamp_(0, w - 1)]
+        colour = colour.reshape(m, gh * gw, 3)
+        best = torch.full((m, h, w), float("inf"), device=dev)
+        lab = torch.zeros((m, h, w), dtype=torch.long, device=dev)
         for dy in (-1, 0, 1):
             ny = (cy + dy).clamp_(0, gh - 1)
             for dx in (-1, 0, 1):
                 nx = (cx + dx).clamp_(0, gw - 1)
-                d = (py[:, None] - sy[ny[:, None], nx[None, :]]) ** 2
-                d += (px[None, :] - sx[ny[:, None], nx[None, :]]) ** 2
+                cell = (ny[:, None] * gw + nx[None, :])[None].expand(m, -1, -1)     # [m,h,w]
+                d = (py - sy.reshape(m, -1).gather(1, cell.reshape(m, -1)).reshape(m, h, w)) ** 2
+                d += (px - sx.reshape(m, -1).gather(1, cell.reshape(m, -1)).reshape(m, h, w)) ** 2
                 upd = d < best
                 best = torch.where(upd, d, best)
-                lab = torch.where(upd, ny[:, None] * gw + nx[None, :], lab)
-        img = colour[lab].to(torch.int16)
-        img += torch.randint(-1, 2, (h, w, 3), device=dev, generator=gen, dtype=torch.int16)
-        out[i] = img.clamp_(0, 255).to(torch.uint8)
+                lab = torch.where(upd, cell, lab)
+        img = colour.gather(1, lab.reshape(m, -1, 1).expand(-1, -1, 3)).reshape(m, h, w, 3).to(torch.int16)
+        img += torch.randint(-1, 2, (m, h, w, 3), device=dev, generator=gen, dtype=torch.int16)
+        out[i0:i0 + m] = img.clamp_(0, 255).to(torch.uint8)
     return out
 
 

@@ -1004,7 +1004,7 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
         // tool, /root/reference/filter_reflectance.py:67-70,118): the float kernels of rf_gf_f32 on
         // float copies of the images, every pass rounded to uint8 like convertTo(CV_8U).  On 8-bit
         // data the float path's double window sums are the same exact integers the 8-bit stage 1
-        // forms, so the bytes are what the 8-bit kernels would give (tests: both against the oracle).
+        // forms, so the bytes are what the 8-bit kernels would give (tested on either side of 120).
         const size_t per_img_f = gf_per_img_via_f32(npx, src_cn);
         if (workspace_bytes < header + per_img_f)
             return fail(RF_E_WORKSPACE, "rf_gf_u8: workspace %zu B < %zu B needed for one image at "
@@ -1039,7 +1039,7 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
     }
     // Stage 2 (box means of alpha/beta), three forms with identical bytes:
     //   row walk + column walk (default for the instantiated radii 1..96)
-    //   chained column walk (debug option "gf_chained": no row-walk kernel, every block takes its row
+    //   chained column walk (debug option "gf_chained", radius 45 and 52 only: no row-walk kernel, every block takes its row
     //       sums from its left neighbour; identical bytes, measured SLOWER - the stagger between
     //       neighbouring blocks costs the L2 sharing of their operand lines, profiles/r04_gf_chained.md)
     //   row-sum / column-sum kernel pair (radius 0 and 97..120; debug option "gf_two_kernel")
@@ -1050,7 +1050,7 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
     const size_t per_img_chained = can_fuse ? gf_per_img_chained(npx, np, nb, h, radius) : 0;
     const size_t per_img_rw = gf_per_img_row_walk(npx, np, nb, h);
     const size_t per_img = gf_per_img_two_kernel(npx, np);
-    const bool chained = can_fuse && debug_get(kDbgGfChained) &&
+    const bool chained = can_fuse && debug_get(kDbgGfChained) && gf_chained_radius(radius) &&
                          workspace_bytes >= header + per_img_chained;
     const bool fused = chained || (can_fuse && workspace_bytes >= header + per_img_rw);
     const size_t per_img_fused = chained ? per_img_chained : per_img_rw;

@@ -388,7 +388,12 @@ __device__ __forceinline__ unsigned gf_chain_tag1(unsigned seed, unsigned j, uns
     return x;
 }
 
-template <int R>
+// (CHAINED is a template parameter: with the choice made at run time the row-walk form of the very
+//  same kernel fetched 41 instead of 29 B/px at the C5 shard - profiles/r04_c5_traffic.md - so the
+//  experiment is compiled apart, and only for the reference's two radii, kGfChainedRadii.)
+constexpr bool gf_chained_radius(int r) { return r == 45 || r == 52; }
+
+template <int R, bool CHAINED = false>
 __global__ __launch_bounds__(128, (R <= 64 ? 2 : 1)) void gf_colwalk_kernel(
     const float *__restrict__ ab, const double *__restrict__ states,
     const uint8_t *__restrict__ guide, uint8_t *__restrict__ dst, int h, int w, int nb,
@@ -410,7 +415,7 @@ __global__ __launch_bounds__(128, (R <= 64 ? 2 : 1)) void gf_colwalk_kernel(
     __shared__ int turn;  // next sub-tile whose column phase may run
     __shared__ int ticket;
 
-    const bool chained = xc.xst != nullptr;
+    constexpr bool chained = CHAINED;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     WalkLds<T> &L = lds[wv];
@@ -859,11 +864,13 @@ void gf_fused_launch(const GfFusedArgs &a)
         hipLaunchKernelGGL(gf_rowhead_kernel<0>, dim3((unsigned)hb, (unsigned)(a.m * a.src_cn)), dim3(64), 0,
                            a.stream, a.ab, const_cast<double *>(a.chain.head), a.h, a.w, R, a.src_cn,
                            a.colour, a.chain.sync);
-        if (!(a.exp_skip & 4))
-            hipLaunchKernelGGL((gf_colwalk_kernel<R>),
-                               dim3(8u * (unsigned)((a.m + 7) / 8) * a.src_cn * a.nb), dim3(128), 0,
-                               a.stream, a.ab, a.states, a.guide, a.dst, a.h, a.w, a.nb, pairs,
-                               a.src_cn, a.colour, a.chain, a.compact);
+        if constexpr (gf_chained_radius(R)) {
+            if (!(a.exp_skip & 4))
+                hipLaunchKernelGGL((gf_colwalk_kernel<R, true>),
+                                   dim3(8u * (unsigned)((a.m + 7) / 8) * a.src_cn * a.nb), dim3(128),
+                                   0, a.stream, a.ab, a.states, a.guide, a.dst, a.h, a.w, a.nb, pairs,
+                                   a.src_cn, a.colour, a.chain, a.compact);
+        }
         return;
     }
     if (!(a.exp_skip & 2))

@@ -887,6 +887,36 @@ def test_gf_fused_stage2_any_radius(env, radius):
         assert torch.equal(a, b), (radius, hh, ww)
 
 
+@pytest.mark.parametrize("radius,eps", [(45, 3.0), (52, 7.0)])
+def test_gf_switches_keep_the_bytes(env, radius, eps):
+    """The alternative forms behind the round-4 switches give the default's bytes (which the other
+    tests hold to the oracle): the chained column walk (no row-walk kernel; blocks hand their row
+    sums to the right through tagged slots), three-channel hand-offs between passes instead of the
+    one-byte image, and one stream - on a batch that mixes grey and colour images, three passes,
+    widths that are not multiples of 16, more images than ticket queues."""
+    from tests import synth
+    rf, co, torch = env
+    h, w = 150, 203
+    n = 11
+    guides = np.stack([synth.flat_guide_u8(h, w, seed=radius + i, cells=14) for i in range(n)])
+    srcs = np.stack([synth.reflectance_like_u8(h, w, seed=100 + i) if i % 3 else
+                     synth.scene_u8(h, w, seed=100 + i) for i in range(n)])
+    g, s = torch.from_numpy(guides).cuda(), torch.from_numpy(srcs).cuda()
+    want = rf.ops.guided_filter_u8(g, s, radius, eps, iterations=3)
+    assert np.array_equal(want[1].cpu().numpy(),
+                          co.guided_filter(guides[1], co.guided_filter(guides[1], co.guided_filter(
+                              guides[1], srcs[1], radius, eps), radius, eps), radius, eps))
+    for opts in ({"gf_chained": 1}, {"gf_no_compact": 1}, {"gf_one_stream": 1},
+                 {"gf_chained": 1, "gf_no_compact": 1, "gf_force_two_streams": 1}):
+        with rf._ffi.debug_options(**opts):
+            got = rf.ops.guided_filter_u8(g, s, radius, eps, iterations=3)
+        assert torch.equal(got, want), opts
+    one = s[:, :, :, :1].contiguous()                      # 1-channel src through the chained walk
+    want1 = rf.ops.guided_filter_u8(g, one, radius, eps)
+    with rf._ffi.debug_options(gf_chained=1):
+        assert torch.equal(rf.ops.guided_filter_u8(g, one, radius, eps), want1)
+
+
 def test_gf_radius_beyond_the_8bit_kernels(env):
     """int(sigma_spatial) is a free parameter of the reference's tool
     (/root/reference/filter_reflectance.py:67-70,118): radii above 120 run the float kernels inside
