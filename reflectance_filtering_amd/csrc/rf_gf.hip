@@ -1160,6 +1160,7 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
             k = std::min<long long>(std::max<long long>(k, 1), h);
             int seg = ceil_div(h, (int)k);
             seg = std::max(seg, std::min(h, std::max(2 * (2 * radius + 1), 32)));  // two windows at least
+            seg = ceil_div(h, ceil_div(h, seg));  // equal segments: a launch ends with its longest one
             if (debug_get(kDbgGfSegRows) > 0)
                 seg = std::min(h, debug_get(kDbgGfSegRows));
             return seg;

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void gf_rowstate_kernel(const float *__restric
                                                           double *__restrict__ states, int h, int w,
                                                           int row_blocks, int np,
                                                           const int *__restrict__ colour, int src_np,
-                                                          int nb)
+                                                          int nb, int streaming)
 {
     constexpr int KS = 2 * R + 1;
     constexpr int F = (KS + 15) & ~15;
@@ -123,12 +123,15 @@ __global__ __launch_bounds__(256) void gf_rowstate_kernel(const float *__restric
 #pragma unroll
         for (int k = 0; k < 4; k++)
         {
-            // (non-temporal: the row walk reads every alpha/beta value exactly once; keeping them out
-            //  of the L2 leaves it to the column walk of the other half of the batch: C5 step 67.9 ->
-            //  67.0 ms.  The same hint on stage 1's alpha/beta STORES costs 35 %.)
+            // (non-temporal for batches far beyond the L2: the row walk reads every alpha/beta value
+            //  exactly once, and keeping them out of the L2 leaves it to the column walk of the other
+            //  half of the batch - C5 step 67.9 -> 67.0 ms.  A small batch, whose alpha/beta stage 1
+            //  has just left in the L2, wants them from there: one 256x256 image 0.47 ms against 0.71.
+            //  The same hint on stage 1's alpha/beta STORES costs 35 %.)
             typedef float f32x4 __attribute__((ext_vector_type(4)));
-            const f32x4 t_ = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(
-                reinterpret_cast<const char *>(S4) + ((srow[k] + (uint32_t)sx) << 4)));
+            const f32x4 *p_ = reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(S4) +
+                                                              ((srow[k] + (uint32_t)sx) << 4));
+            const f32x4 t_ = streaming ? __builtin_nontemporal_load(p_) : *p_;
             buf[k] = make_float4(t_.x, t_.y, t_.z, t_.w);
         }
     };
@@ -876,7 +879,8 @@ void gf_fused_launch(const GfFusedArgs &a)
     if (!(a.exp_skip & 2))
         hipLaunchKernelGGL((gf_rowstate_kernel<R>), dim3((unsigned)(a.m * a.src_cn * row_blocks)),
                            dim3(256), 0, a.stream, a.ab, a.states, a.h, a.w, row_blocks, np, a.colour,
-                           np, a.nb);
+                           np, a.nb,
+                           (size_t)a.m * np * a.h * a.w * sizeof(float) > ((size_t)256 << 20) ? 1 : 0);
     if (!(a.exp_skip & 4))
         hipLaunchKernelGGL((gf_colwalk_kernel<R>), dim3(8u * (unsigned)((pairs + 7) / 8) * a.src_cn),
                        dim3(128), 0, a.stream, a.ab, a.states, a.guide, a.dst, a.h, a.w, a.nb, pairs,

@@ -1327,11 +1327,16 @@ __global__ __launch_bounds__(1024) void jbf_tile64_kernel(
         }
         if constexpr (TH != 64)
             return;  // strips are only launched when the one-pass colour tile fits
-        // ---- colour src: 64/crows passes of crows rows with 8-byte texels (crows = 32 when
-        //      the LDS allows it, i.e. two halves run by threads 0..511) ----
-        uint2 *tile8 = reinterpret_cast<uint2 *>(tile_raw);
+        // ---- colour src whose one-pass tile does not fit (row pitch 176: radius 37..52, e.g. the
+        //      reference's c15 s28 -> radius 42 on a colour reflectance, /root/reference/README.md:64):
+        //      64/crows passes of crows rows, the same two planes of 6 bytes per texel and the same
+        //      asm tap loop as the one-pass form, run by threads 0 .. 16*crows-1 while all threads
+        //      stage.  (Round 3 had 8-byte texels here, which only left room for 16-row passes at
+        //      radius 42 and ran the compiler-scheduled loop: 3.9x the time per tap of the radius-33
+        //      colour loop, profiles/r04_bench_other.json.) ----
         float *lut_c = reinterpret_cast<float *>(smem + kT64Lds - nz * CREP * 4);
         const int tlh8 = crows + 2 * radius;
+        uint16_t *plane_b = reinterpret_cast<uint16_t *>(tile_raw + (size_t)tlh8 * TLW * 4);
         for (int half = 0; half * crows < 64; half++) {
             const int y0 = tile_y0 + crows * half;
             if (y0 >= h)
@@ -1346,8 +1351,10 @@ __global__ __launch_bounds__(1024) void jbf_tile64_kernel(
                 uint32_t jv[4], sv[4];
                 load_tile_quad(joint, src, img, gy, tile_x0 - r4 + 4 * k, w, jcn, 3, border, jv, sv);
 #pragma unroll
-                for (int u = 0; u < 4; u++)
-                    tile8[ry * TLW + u * Q4 + k] = make_uint2(jv[u], sv[u]);
+                for (int u = 0; u < 4; u++) {
+                    tile4[ry * TLW + u * Q4 + k] = jv[u] | (sv[u] << 24);
+                    plane_b[ry * TLW + u * Q4 + k] = (uint16_t)(sv[u] >> 8);
+                }
             }
             __syncthreads();
             if (tid < 16 * crows) {
@@ -1355,7 +1362,7 @@ __global__ __launch_bounds__(1024) void jbf_tile64_kernel(
 #pragma unroll
                 for (int p = 0; p < kPix; p++) {
                     const int X = 4 * tx + p + r4;
-                    jc[p] = tile8[(ty + radius) * TLW + (X & 3) * Q4 + (X >> 2)].x;
+                    jc[p] = tile4[(ty + radius) * TLW + (X & 3) * Q4 + (X >> 2)] & 0x00ffffffu;
                 }
                 float sum[kPix][3], wsum[kPix];
 #pragma unroll
@@ -1364,9 +1371,16 @@ __global__ __launch_bounds__(1024) void jbf_tile64_kernel(
                     sum[p][0] = sum[p][1] = sum[p][2] = 0.f;
                 }
                 const uint32_t lut_lane_addr = lds_addr(lut_c) + (uint32_t)(tid & (CREP - 1)) * 4u;
-                const uint32_t tile_lane_addr = lds_addr(tile8) + (uint32_t)tx * 8u;
-                jbf_tap_loop<3, CREP, false, TLW, 8>(lut_lane_addr, sw_addr0, tile_lane_addr, 0u, jc,
-                                                     0u, ty, radius, r4, sw_len, hwtab, sum, wsum);
+                if (flags & kJbfCompilerLoop)  // test aid: compiler-scheduled loop instead of the asm one
+                    jbf_tap_loop<3, CREP, false, TLW, 6>(lut_lane_addr, sw_addr0,
+                                                         lds_addr(tile4) + (uint32_t)tx * 4u,
+                                                         lds_addr(plane_b) + (uint32_t)tx * 2u, jc, 0u,
+                                                         ty, radius, r4, sw_len, hwtab, sum, wsum);
+                else
+                    jbf_tap_loop_rgb6<CREP, TLW>(lut_lane_addr, sw_addr0,
+                                                 lds_addr(tile4) + (uint32_t)tx * 4u,
+                                                 lds_addr(plane_b) + (uint32_t)tx * 2u, jc, ty, radius,
+                                                 r4, sw_len, hwtab, sum, wsum);
                 store_quad<3, 3>(dst, img, y0 + ty, tile_x0 + 4 * tx, h, w, sum, wsum, flags);
             }
         }
@@ -1479,7 +1493,7 @@ int tile64_fits(const JbfTables &t, int nz, int grep, int crep, int scn, int tlw
         return 0;
     for (int crows = 32; crows >= 8; crows >>= 1) {
         const size_t col =
-            sw_bytes + (size_t)tlw * (crows + 2 * t.radius) * 8 + (size_t)nz * crep * 4;
+            sw_bytes + (size_t)tlw * (crows + 2 * t.radius) * 6 + (size_t)nz * crep * 4;
         if (col <= (size_t)kT64Lds)
             return crows;
     }
