@@ -129,3 +129,24 @@ def test_live_traffic_helpers(tmp_path, monkeypatch):
     monkeypatch.setenv("ROCP_TOOL_LIBRARIES", "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so")
     assert bench.being_profiled()
     assert bench.parse_args([]).traffic == "auto"
+
+
+def test_flat_guide_is_seeded_voronoi_cells():
+    """C5's guidance: seeded Voronoi cells of flat colour +-1 dither, 200 - 2,000
+    regions by image size, deterministic, generated with torch on whatever device the scene is on."""
+    import numpy as np
+    import torch
+    bench = _load_bench() if "_load_bench" in globals() else __import__("bench")
+    scene, _ = bench.synth_batch(torch, 2, 540, 960, 77, torch.device("cpu"))
+    g = bench.flat_guide(scene)
+    assert g.dtype == torch.uint8 and g.shape == scene.shape
+    assert torch.equal(g, bench.flat_guide(scene))                     # seeded
+    assert not torch.equal(g[0], g[1])
+    a = g[0].numpy().astype(np.int16)
+    flat = np.abs(a[:, 1:] - a[:, :-1]).max(axis=2) <= 2             # within the dither of the left neighbour
+    assert flat.mean() > 0.95
+    # count regions: connected runs of near-equal colour along rows are long (cells ~ 90 px wide)
+    runs = (~flat).sum(axis=1).mean()                                  # cell borders crossed per row
+    assert 2 <= runs <= 40
+    coarse = len(np.unique((a // 8).reshape(-1, 3), axis=0))
+    assert 50 <= coarse <= 2000 * 8                                    # hundreds of cells, not a posterised scene
