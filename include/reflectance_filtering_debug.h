@@ -7,7 +7,7 @@
  * not meant to be flipped while other threads are inside the library, and all default to 0.
  *
  *   "gf_two_kernel"      guided filter: row-sum / column-sum kernel pair for every radius (the
- *                        default fuses stage 2 for radius 45 and 52); identical bytes
+ *                        default fuses stage 2 for every radius 1..96); identical bytes
  *   "jbf_compiler_loop"  joint bilateral: compiler-scheduled tap loop; identical bytes
  *   "jbf_tile64_only"    joint bilateral: no strip tiles at the image remainder; identical bytes
  *   "jbf_tune"           joint bilateral: kernel-variant override 1..7 (tools/jbf_tune.py)
@@ -25,8 +25,17 @@
  *                        statistics of its first pass in the workspace (36 B per pixel) and later
  *                        passes box-sum only the src quantities; identical bytes, measured slower
  *                        (profiles/r03_gf_guide_cache.md), off by default
+ *   "gf_chained"         guided filter, radius 45 / 52: the column walk without a row-walk kernel
+ *                        (every 16-column block takes its row sums from its left neighbour through
+ *                        tagged slots); identical bytes, measured slower
+ *                        (profiles/r04_gf_chained.md), off by default
+ *   "gf_no_compact"      guided filter: grey images of a 3-channel src are read and handed from pass
+ *                        to pass as three channels (the default keeps them as one byte per pixel in
+ *                        the workspace); identical bytes
  *   "jbf_stage_only"     joint bilateral: stage the tile and return WITHOUT WRITING dst
  *                        (tools/jbf_tune.py --stage-only, timing only)
+ *   "gf_exp_skip"        guided filter, TIMING ONLY, WRONG RESULTS: bit 0 no stage 1, bit 1 no row
+ *                        walk, bit 2 no column walk (tools/gf_c5_exp.py)
  */
 #ifndef REFLECTANCE_FILTERING_DEBUG_H
 #define REFLECTANCE_FILTERING_DEBUG_H
