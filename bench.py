@@ -404,7 +404,8 @@ class Workload:
                                                         workspace=self.ws)
             self.bytes_per_px = GF_BYTES_PER_PX_X3
             self.name = ("3x guided filter c=3.0 s=45.0 (radius 45, eps 3), batch %d x %dx%d per "
-                         "GPU, piecewise-constant guide, grey map as src" % (n, w, h))
+                         "GPU, piecewise-constant guide (seeded Voronoi cells of flat colour +-1), grey map as src"
+                         % (n, w, h))
         else:  # chain
             self.scene = scene
             del grey
