@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define RF_VERSION 102 /* 0.1.2 */
+#define RF_VERSION 103 /* 0.1.3 */
 
 /* return codes */
 #define RF_OK 0

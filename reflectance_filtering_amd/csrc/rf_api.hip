@@ -80,7 +80,13 @@ extern "C" int rf_debug_clock_probe(unsigned long long *out2, int micros, void *
     return RF_OK;
 }
 
+// (a development build - make GF_DEV_ONLY=<radius>: one radius of the fused guided filter only -
+//  says so in its version, and __graft_entry__.build() refuses to accept it)
+#ifdef RF_GF_DEV_ONLY
+extern "C" int rf_version(void) { return RF_VERSION | 0x40000000; }
+#else
 extern "C" int rf_version(void) { return RF_VERSION; }
+#endif
 
 extern "C" const char *rf_last_error(void) { return rf::last_error_buf(); }
 

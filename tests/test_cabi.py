@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(built):
     assert set(names) == set(_ffi.EXPORTS)
     for name in names:
         assert getattr(lib, name) is not None
-    assert lib.rf_version() == 102
+    assert lib.rf_version() == 103
     out = subprocess.check_output(["nm", "-D", "--defined-only", _ffi.LIB_PATH]).decode()
     for name in names:
         assert re.search(r"\bT %s\b" % name, out), name
