@@ -887,6 +887,25 @@ def test_gf_fused_stage2_any_radius(env, radius):
         assert torch.equal(a, b), (radius, hh, ww)
 
 
+def test_gf_tiny_images_through_every_path(env):
+    """Images far smaller than the window (multi-bounce borders, one column block, fewer rows than a
+    sub-tile) through the fused path with the one-byte hand-off (grey 3-channel src, three passes),
+    the two-kernel pair (radius 100) and the float kernels (radius 150) - against the oracle."""
+    from tests import synth
+    rf, co, torch = env
+    for (h, w) in ((1, 1), (1, 7), (5, 1), (3, 2), (17, 33)):
+        guide = synth.scene_u8(h, w, seed=h * 100 + w)
+        grey = synth.reflectance_like_u8(h, w, seed=h * 100 + w + 1)
+        g = torch.from_numpy(guide[None]).cuda()
+        s = torch.from_numpy(grey[None]).cuda()
+        for radius, eps, iters in ((45, 3.0, 3), (100, 7.0, 2), (150, 3.0, 2)):
+            got = rf.ops.guided_filter_u8(g, s, radius, eps, iterations=iters).cpu().numpy()[0]
+            cur = grey
+            for _ in range(iters):
+                cur = co.guided_filter(guide, cur, radius, eps)
+            assert np.array_equal(got, cur), (h, w, radius)
+
+
 @pytest.mark.parametrize("radius,eps", [(45, 3.0), (52, 7.0)])
 def test_gf_switches_keep_the_bytes(env, radius, eps):
     """The alternative forms behind the round-4 switches give the default's bytes (which the other
