@@ -628,8 +628,9 @@ def live_traffic_config(cfg, batch, deadline_s=90.0):
     return ({"traffic": total,
              "traffic_source": "measured by this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child "
                                "passes of one step of `bench.py --config %s --batch %d` (FETCH_SIZE "
-                               "doubled for gfx950), every dispatch of a library kernel added up"
-                               % (cfg, batch),
+                               "doubled for gfx950), every dispatch of a library kernel added up; the "
+                               "child keeps the guided filter on one stream (counter passes serialise "
+                               "kernels anyway; the two-stream step crashed rocprofv3)" % (cfg, batch),
              "kernels": kernels}, None)
 
 
