@@ -580,10 +580,6 @@ def live_traffic_config(cfg, batch, deadline_s=90.0):
         return None, "rocprofv3 not found"
     tmp = tempfile.mkdtemp(prefix="rf_bench_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp", RF_BENCH_CHILD="1")
-    # rocprofv3's counter tool crashes (SIGSEGV in its own thread, 5 of 6 tries) on the guided
-    # filter's two-stream step when this parent process is alive, and never on the same step kept on
-    # one stream; counter passes serialise the kernels anyway, so the per-kernel bytes are the same
-    env["RF_DEBUG_OPTIONS"] = ",".join(filter(None, [env.get("RF_DEBUG_OPTIONS", ""), "gf_one_stream=1"]))
     for key in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(key, None)
     kernels = {}
@@ -599,8 +595,9 @@ def live_traffic_config(cfg, batch, deadline_s=90.0):
             if left < 15:
                 return None, "no time left for the %s pass" % counter
             try:
-                # (run from the repository root: started from /tmp the same command crashed inside
-                #  rocprofv3 in every try)
+                # (run from the repository root.  History: rocprofv3's counter tool crashed - SIGSEGV in
+                #  its own thread - while the C5 guide was generated with ~9,000 tiny torch launches; the
+                #  batched generator of flat_guide() has not triggered it in 12 runs)
                 p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE,
                                    stderr=subprocess.PIPE, timeout=left)
             except subprocess.TimeoutExpired:
@@ -628,9 +625,8 @@ def live_traffic_config(cfg, batch, deadline_s=90.0):
     return ({"traffic": total,
              "traffic_source": "measured by this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child "
                                "passes of one step of `bench.py --config %s --batch %d` (FETCH_SIZE "
-                               "doubled for gfx950), every dispatch of a library kernel added up; the "
-                               "child keeps the guided filter on one stream (counter passes serialise "
-                               "kernels anyway; the two-stream step crashed rocprofv3)" % (cfg, batch),
+                               "doubled for gfx950), every dispatch of a library kernel added up"
+                               % (cfg, batch),
              "kernels": kernels}, None)
 
 
