@@ -85,7 +85,7 @@ def test_joint_bilateral_random_cases_match_the_oracle(env):
         jcn, scn = int(rng.choice([1, 3])), int(rng.choice([1, 3]))
         joint = _image(rng, h, w, jcn, int(rng.integers(0, 4)))
         src = _image(rng, h, w, scn, int(rng.integers(0, 3)))
-        ss = float(rng.choice([22.0, 28.0, 5.0, 12.3, 34.0, 1.0]))
+        ss = float(rng.choice([22.0, 28.0, 5.0, 12.3, 34.0, 1.0, 25.0, 31.0]))  # radius 33 42 8 18 51 2 38 46
         sc = float(rng.choice([20.0, 15.0, 4.0, 60.0, 0.5]))
         d = int(rng.choice([-1, -1, 5, 9, 31]))
         border = int(rng.choice([0, 1, 2, 3, 4]))
