@@ -19,14 +19,18 @@
 //            radius 1..96: gf_rowstate_kernel<R> + gf_colwalk_kernel<R> (rf_gf_fused.hpp,
 //            instantiated per radius in rf_gf_fused_inst.hip) - the double row sums never reach
 //            HBM; radius 97..120 and 0: gf_rowsum_kernel + gf_colsum_apply_kernel, which write
-//            every row sum (8 B per pixel and plane) and read it twice.
+//            every row sum (8 B per pixel and plane) and read it twice; radius 121..4096: the
+//            float kernels of rf_gf_f32 on float copies of the images, each pass rounded to uint8
+//            (on 8-bit data their double window sums are the same exact integers).
 //
 // Grey sources: the reference filters the CNN's grey `-r.png`, which imread turns into three
 // identical channels.  The src channels never mix, so identical channels give identical
 // outputs; gf_grey_probe_kernel marks such images (a device-side flag, no host round trip) and
 // they run the one-channel instantiation with the result byte written three times (1/3 of the
 // per-channel planes).  Every stage is launched in both instantiations; workgroups of the one
-// that does not apply to their image exit at once.
+// that does not apply to their image exit at once.  The probe also leaves channel 0 of every image
+// as one byte per pixel in the workspace: that copy is what stage 1 reads for a grey image and
+// what the passes of an iterated call hand on, until the last pass writes dst.
 #include "rf_gf_fused.hpp"
 
 #include <algorithm>
