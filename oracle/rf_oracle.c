@@ -444,6 +444,131 @@ static void rfo_box_mean(const float *src, float *dst, int h, int w, int r)
     free(rows);
 }
 
+/*
+ * Exactness census of the stage-2 box means (tools/gf_exactness.py; measurement aid, not part of
+ * the restatement).  rfo_box_mean's arithmetic with every double addition / subtraction checked by
+ * TwoSum: an operation is "inexact" when it rounded.  A chain none of whose operations rounded
+ * holds the mathematically exact window sum, i.e. a value that does not depend on the order.
+ *   c[0] rows              c[1] rows with a rounded operation
+ *   c[2] row operations    c[3] rounded row operations
+ *   c[4] columns           c[5] columns with a rounded operation
+ *   c[6] column operations c[7] rounded column operations
+ *   c[8] rows that pass the order-free sufficient test: every non-zero value of the row is a
+ *        multiple of 2^e (e = its float exponent - 23) and ks * max|v| < 2^(e_min + 53)
+ *   c[9] planes            c[10] planes with no rounded operation at all
+ */
+static unsigned long long g_rfo_census[16];
+static int g_rfo_census_on;
+void rfo_census(int on, unsigned long long *out16)
+{
+    if (out16)
+        for (int i = 0; i < 16; i++)
+            out16[i] = g_rfo_census[i];
+    if (on)
+        for (int i = 0; i < 16; i++)
+            g_rfo_census[i] = 0;
+    g_rfo_census_on = on;
+}
+static inline int rfo_add_rounded(double a, double b, double s)
+{
+    double bb = s - a;
+    double err = (a - (s - bb)) + (b - bb);
+    return err != 0.0;
+}
+static void rfo_box_mean_census(const float *src, float *dst, int h, int w, int r)
+{
+    unsigned long long c[16] = {0};
+    int ks = 2 * r + 1;
+    double scale = 1.0 / ((double)ks * (double)ks);
+    double *rows = (double *)malloc(sizeof(double) * (size_t)h * w);
+    int ew = w + ks - 1;
+    float *ext = (float *)malloc(sizeof(float) * ew);
+    for (int y = 0; y < h; y++) {
+        const float *S0 = src + (size_t)y * w;
+        double *D = rows + (size_t)y * w;
+        int emin = 10000;
+        float vmax = 0.f;
+        for (int x = 0; x < ew; x++) {
+            float v = S0[rfo_border_interpolate(x - r, w, RFO_BORDER_REFLECT)];
+            ext[x] = v;
+            if (v != 0.f) {
+                int e;
+                (void)frexpf(v, &e); /* |v| in [2^(e-1), 2^e): lsb weight 2^(e-24) */
+                if (e - 24 < emin)
+                    emin = e - 24;
+                if (fabsf(v) > vmax)
+                    vmax = fabsf(v);
+            }
+        }
+        if (vmax == 0.f || (double)ks * (double)vmax < ldexp(1.0, emin + 53))
+            c[8]++;
+        unsigned long long bad = 0, ops = 0;
+        double s = 0;
+        for (int i = 0; i < ks; i++) {
+            double t = s + (double)ext[i];
+            bad += rfo_add_rounded(s, (double)ext[i], t);
+            ops++;
+            s = t;
+        }
+        D[0] = s;
+        for (int i = 0; i < w - 1; i++) {
+            double a = (double)ext[i + ks], b = (double)ext[i];
+            double d = a - b;
+            bad += rfo_add_rounded(a, -b, d);
+            double t = s + d;
+            bad += rfo_add_rounded(s, d, t);
+            ops += 2;
+            s = t;
+            D[i + 1] = s;
+        }
+        c[0]++;
+        c[1] += bad != 0;
+        c[2] += ops;
+        c[3] += bad;
+    }
+    double *SUM = (double *)calloc(w, sizeof(double));
+    unsigned long long *cbad = (unsigned long long *)calloc(w, sizeof(unsigned long long));
+    for (int yy = -r; yy < r; yy++) {
+        const double *Sp = rows + (size_t)rfo_border_interpolate(yy, h, RFO_BORDER_REFLECT) * w;
+        for (int i = 0; i < w; i++) {
+            double t = SUM[i] + Sp[i];
+            cbad[i] += rfo_add_rounded(SUM[i], Sp[i], t);
+            SUM[i] = t;
+        }
+        c[6] += w;
+    }
+    for (int y = 0; y < h; y++) {
+        const double *Sp = rows + (size_t)rfo_border_interpolate(y + r, h, RFO_BORDER_REFLECT) * w;
+        const double *Sm = rows + (size_t)rfo_border_interpolate(y - r, h, RFO_BORDER_REFLECT) * w;
+        float *D = dst + (size_t)y * w;
+        for (int i = 0; i < w; i++) {
+            double s0 = SUM[i] + Sp[i];
+            cbad[i] += rfo_add_rounded(SUM[i], Sp[i], s0);
+            D[i] = (float)(s0 * scale);
+            double t = s0 - Sm[i];
+            cbad[i] += rfo_add_rounded(s0, -Sm[i], t);
+            SUM[i] = t;
+        }
+        c[6] += 2 * (unsigned long long)w;
+    }
+    for (int i = 0; i < w; i++) {
+        c[4]++;
+        c[5] += cbad[i] != 0;
+        c[7] += cbad[i];
+    }
+    c[9] = 1;
+    c[10] = (c[3] == 0 && c[7] == 0);
+    free(cbad);
+    free(SUM);
+    free(ext);
+    free(rows);
+#ifdef _OPENMP
+#pragma omp critical(rfo_census)
+#endif
+    for (int i = 0; i < 16; i++)
+        g_rfo_census[i] += c[i];
+}
+
 /* RFO_VAR_GF_FLOAT_BOXSUM: the same two running sums held in float (RowSum<float,float>,
  * ColumnSum<float,float>: out = s * (float)scale) */
 static void rfo_box_mean_float_sums(const float *src, float *dst, int h, int w, int r)
@@ -669,10 +794,11 @@ static int gf_core(const float *guide_f, const float *src_f, uint8_t *dst, float
 #pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
     for (int t = 0; t < src_cn * 4; t++) {
         int s = t / 4, g = t % 4;
-        if (g == 3)
-            rfo_box_mean(p[s], p[s], h, w, radius);
+        float *pl = g == 3 ? p[s] : al[s][g];
+        if (g_rfo_census_on && !(g_rfo_variants & RFO_VAR_GF_FLOAT_BOXSUM))
+            rfo_box_mean_census(pl, pl, h, w, radius); /* same values, operations counted */
         else
-            rfo_box_mean(al[s][g], al[s][g], h, w, radius);
+            rfo_box_mean(pl, pl, h, w, radius);
     }
     /* ApplyTransform: q = beta + sum_g alpha_g * I_g, g ascending */
     for (int s = 0; s < src_cn; s++)

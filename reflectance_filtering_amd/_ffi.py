@@ -10,9 +10,10 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# RF_LIB_PATH: development aid for A/B timing of two builds of the library on one box
-# (tools/gf_c5_exp.py in two processes); it still has to be a librf_hip.so, nothing else loads.
-LIB_PATH = os.environ.get("RF_LIB_PATH") or os.path.join(_HERE, "librf_hip.so")
+# The one library this package loads.  (A/B timing of two builds: tools/gf_c5_exp.py --lib PATH sets
+# this attribute before the first call - announced on stderr, version checked; no environment
+# variable redirects the shipped loader.)
+LIB_PATH = os.path.join(_HERE, "librf_hip.so")
 
 RF_OK, RF_E_BADARG, RF_E_UNSUPPORTED, RF_E_WORKSPACE, RF_E_HIP = 0, -1, -2, -3, -4
 BORDER_CONSTANT, BORDER_REPLICATE, BORDER_REFLECT, BORDER_WRAP, BORDER_REFLECT_101 = range(5)

@@ -41,7 +41,8 @@ extern "C" int rf_debug_option(const char *name, int value)
                                                       "cnn_lds_columns",   "gf_seg_rows",
                                                       "gf_one_stream",     "gf_force_two_streams",
                                                       "gf_guide_cache",    "gf_chained",        "gf_no_compact",
-                                                      "gf_exp_skip"};
+                                                      "gf_exp_skip",       "gf_stagger",        "gf_parts",
+                                                      "gf_s1_cap",         "gf_s1_min_wgs"};
     static_assert(sizeof(names) / sizeof(names[0]) == rf::kDbgCount, "one name per DebugOption");
     if (name)
         for (int i = 0; i < rf::kDbgCount; i++)

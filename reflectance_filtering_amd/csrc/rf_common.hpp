@@ -87,6 +87,10 @@ enum DebugOption {
     kDbgGfChained,         // guided filter: chained column walk (no row-walk kernel; measured slower, profiles/r04_gf_chained.md)
     kDbgGfNoCompact,       // guided filter: iterated calls hand grey images on as three channels in dst (not one byte per pixel)
     kDbgGfExpSkip,         // guided filter, TIMING ONLY (wrong results): bit 0 no stage 1, bit 1 no row states, bit 2 no column walk
+    kDbgGfStagger,         // guided filter: staggered two-stream schedule (stage 1 of one part beside the walks of the other)
+    kDbgGfParts,           // guided filter, staggered schedule: parts per chunk (even, default 2)
+    kDbgGfS1Cap,           // guided filter: stage-1 workgroups per CU (dynamic-LDS pad), 0 = whatever fits
+    kDbgGfS1MinWgs,        // guided filter: workgroups a stage-1 launch should at least have (0 = chosen by the library)
     kDbgCount
 };
 int debug_get(int id);

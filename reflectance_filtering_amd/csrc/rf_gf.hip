@@ -35,6 +35,7 @@
 
 #include <algorithm>
 #include <mutex>
+#include <vector>
 
 namespace rf {
 namespace {
@@ -926,6 +927,7 @@ constexpr size_t kGfSyncBytes = 256;
 // radii above this run the float kernels (uint32 window sums: (2r+1)^2 * 255^2 < 2^32; strip width)
 constexpr int kGfMaxRadiusU8 = 120;
 // ... on float copies of guide, src and result + the float kernels' own planes and row sums
+constexpr size_t kGfF32Slack = 16;  // once per workspace: alignment of the float kernels' scratch
 size_t gf_per_img_via_f32(size_t npx, int src_cn)
 {
     return npx * ((3 + 2 * (size_t)src_cn) * sizeof(float) +
@@ -964,7 +966,7 @@ extern "C" size_t rf_gf_workspace_bytes(int n, int h, int w, int guide_cn, int s
         imgs = cap / per_img;
     if (imgs < 1)
         imgs = 1;
-    return rf::gf_header_bytes(n) + imgs * per_img;
+    return rf::gf_header_bytes(n) + imgs * per_img + (radius > rf::kGfMaxRadiusU8 ? rf::kGfF32Slack : 0);
 }
 
 extern "C" int rf_gf_f32(const float *guide, const float *src, float *dst, int n, int h, int w,
@@ -1010,18 +1012,21 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
         // data the float path's double window sums are the same exact integers the 8-bit stage 1
         // forms, so the bytes are what the 8-bit kernels would give (tested on either side of 120).
         const size_t per_img_f = gf_per_img_via_f32(npx, src_cn);
-        if (workspace_bytes < header + per_img_f)
+        if (workspace_bytes < header + per_img_f + kGfF32Slack)
             return fail(RF_E_WORKSPACE, "rf_gf_u8: workspace %zu B < %zu B needed for one image at "
-                        "radius %d", workspace_bytes, header + per_img_f, radius);
+                        "radius %d", workspace_bytes, header + per_img_f + kGfF32Slack, radius);
         const size_t f32_ws = npx * (9 + 4 * (size_t)src_cn) * (sizeof(float) + sizeof(double));
-        int chunk = (int)std::min<size_t>((size_t)n, (workspace_bytes - header) / per_img_f);
+        // (kGfF32Slack: the float kernels' scratch starts with double row sums, so the float copies
+        //  in front of it are rounded up to 16 bytes - an odd pixel count would leave it 4-aligned)
+        int chunk = (int)std::min<size_t>((size_t)n, (workspace_bytes - header - kGfF32Slack) / per_img_f);
         char *ws0 = static_cast<char *>(workspace) + header;
         for (int i0 = 0; i0 < n; i0 += chunk) {
             const int m = std::min(chunk, n - i0);
             float *gF = reinterpret_cast<float *>(ws0);
             float *sF = gF + (size_t)m * npx * 3;
             float *dF = sF + (size_t)m * npx * src_cn;
-            void *fw = dF + (size_t)m * npx * src_cn;
+            const size_t copies = ((size_t)m * npx * (3 + 2 * (size_t)src_cn) * sizeof(float) + 15) & ~(size_t)15;
+            void *fw = ws0 + copies;
             const size_t cg = (size_t)m * npx * 3, cs = (size_t)m * npx * src_cn;
             const unsigned bg = (unsigned)std::min<size_t>((cg + 255) / 256, 65535);
             const unsigned bs = (unsigned)std::min<size_t>((cs + 255) / 256, 65535);
@@ -1109,41 +1114,68 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
     const int probe_blocks = (int)std::min<size_t>(1024, (npx / 4 + 255) / 256 + 1);
 
     // One part = m images starting at i0, their scratch at ws, every launch on st.
-    auto run_part = [&](int i0, int m, int m_fill, char *ws, hipStream_t st) {
-        const int *colour = colour_all ? colour_all + i0 : nullptr;
+    // One part = m images starting at i0, their scratch at ws, every launch on st.  A part is
+    // enqueued in steps - probe, then per pass stage 1 and stage 2 - so that the schedules below can
+    // interleave the steps of several parts.
+    struct Part {
+        int i0, m;
+        char *ws;
+        hipStream_t st;
+        // derived (part_setup)
+        const int *colour;
+        double *rows;
+        float *ab, *gs;
+        uint8_t *cmp;
+        GfChain xc;
+        const uint8_t *g0;
+        uint8_t *d0;
+        int seg_rows1, seg_rows3;
+    };
+    // stage-1 occupancy cap (debug option "gf_s1_cap" = workgroups per CU, 0 = whatever fits): a
+    // dynamic-LDS pad makes one more workgroup than the cap exceed the CU's 160 KB, which leaves
+    // registers and LDS on every CU for the walk kernels of the other part (see the schedule below)
+    const int s1_cap = debug_get(kDbgGfS1Cap);
+    auto s1_pad = [&](size_t static_lds) -> unsigned {
+        if (s1_cap < 1 || s1_cap > 3)
+            return 0;
+        const size_t want = (size_t)163840 / (s1_cap + 1) + 1536;
+        return want > static_lds ? (unsigned)(want - static_lds) : 0u;
+    };
+    const unsigned pad1 = s1_pad(sizeof(uint32_t) * (13 * (stage1_threads(1) * stage1_cols(1) + 1) + 13 * 4));
+    const unsigned pad3 = s1_pad(sizeof(uint32_t) * (21 * (stage1_threads(3) * stage1_cols(3) + 1) + 21 * 4));
+    auto part_setup = [&](Part &P, int m_fill) {
+        const int i0 = P.i0, m = P.m;
+        char *ws = P.ws;
+        P.colour = colour_all ? colour_all + i0 : nullptr;
         // two-kernel form: [row sums (double)][alpha/beta]; row walk: [states (double)][alpha/beta];
         // chained: [sync words][hand-off words][head sums][alpha/beta]
-        double *rows = reinterpret_cast<double *>(ws);
-        float *ab = reinterpret_cast<float *>(rows + (fused ? (size_t)m * np * nb * h
-                                                            : (size_t)m * np * npx));
-        GfChain xc = {nullptr, nullptr, nullptr};
+        P.rows = reinterpret_cast<double *>(ws);
+        P.ab = reinterpret_cast<float *>(P.rows + (fused ? (size_t)m * np * nb * h
+                                                          : (size_t)m * np * npx));
+        P.xc = GfChain{nullptr, nullptr, nullptr};
         if (chained) {
-            xc.sync = reinterpret_cast<unsigned *>(ws);
-            xc.xst = reinterpret_cast<unsigned long long *>(ws + kGfSyncBytes);
+            P.xc.sync = reinterpret_cast<unsigned *>(ws);
+            P.xc.xst = reinterpret_cast<unsigned long long *>(ws + kGfSyncBytes);
             double *head = reinterpret_cast<double *>(
                 ws + kGfSyncBytes + (size_t)m * gf_chain_xst_bytes(src_cn, nb, h, radius));
-            xc.head = head;
-            ab = reinterpret_cast<float *>(head + (size_t)m * np * h);
-            rows = nullptr;
+            P.xc.head = head;
+            P.ab = reinterpret_cast<float *>(head + (size_t)m * np * h);
+            P.rows = nullptr;
         }
-        float *gs = keep_gs ? ab + (size_t)m * np * npx : nullptr;  // [m][h][kGsFloats][w]
+        P.gs = keep_gs ? P.ab + (size_t)m * np * npx : nullptr;  // [m][h][kGsFloats][w]
         // grey 3-channel images of an iterated call: the passes hand their result on as one byte per
-        // pixel (see cmp_bytes below)
-        uint8_t *cmp = cmp_bytes ? reinterpret_cast<uint8_t *>(ab + (size_t)m * np * npx) +
-                                       (keep_gs ? (size_t)m * gs_bytes : 0)
-                                 : nullptr;
-        const uint8_t *g0 = guide + (size_t)i0 * npx * 3;
-        uint8_t *d0 = dst + (size_t)i0 * npx * src_cn;
-        // the part's grey probe (flags zeroed by the caller's stream before the fork); with the
-        // one-byte hand-off it also leaves every image's channel 0 in cmp for the first pass
-        if (colour_all != nullptr)
-            hipLaunchKernelGGL(gf_grey_probe_kernel, dim3(probe_blocks, m), dim3(256), 0, st,
-                               src + (size_t)i0 * npx * 3, colour_all + i0, npx, cmp);
+        // pixel (see cmp_bytes above)
+        P.cmp = cmp_bytes ? reinterpret_cast<uint8_t *>(P.ab + (size_t)m * np * npx) +
+                                (keep_gs ? (size_t)m * gs_bytes : 0)
+                          : nullptr;
+        P.g0 = guide + (size_t)i0 * npx * 3;
+        P.d0 = dst + (size_t)i0 * npx * src_cn;
         // row segments: enough workgroups to fill 256 CUs, but segments no shorter than 2r+1.
         // (tools/gf_seg_sweep.py: a pass is flat within 3 % between 34 and 135 rows per segment at
         // 4K - the 2r warm-up rows of a segment are cheap - and slower above; a model that picks
         // the segment count by whole rounds of resident workgroups was no better.)
-        // (m_fill: the images in flight on the device, i.e. both halves of a chunk)
+        // (m_fill: the images whose stage 1 is in flight on the device together - both halves of a
+        // chunk in the aligned schedule, the part alone in the staggered one)
         // How many workgroups that is depends on the instantiation (each figure measured against
         // its alternatives in one process).  1-channel kernels: the C5 shard (3 passes; chunks of 37
         // images, 18 + 19 per half) 14.1 / 14.5 / 14.1-14.3 / 14.0-14.2 GP/s at 135 / 270 / 540 / 1080
@@ -1158,6 +1190,8 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
         //  step, 540 rows 69.1, 405 / 180 / 1080 rows 71.5 / 71.7 / 72.8 - so the segment COUNT is now the
         //  smallest that still gives every place of the chip about one workgroup, not a power of two)
         auto pick_seg = [&](int strips_k, long long min_wgs, int cap) {
+            if (debug_get(kDbgGfS1MinWgs) > 0)
+                min_wgs = debug_get(kDbgGfS1MinWgs);
             const long long per_seg = std::max<long long>(1, (long long)strips_k * m_fill);
             long long k = (min_wgs + per_seg - 1) / per_seg;          // segments per image
             k = std::max<long long>(k, ceil_div(h, cap));
@@ -1171,69 +1205,101 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
                 seg = std::min(h, debug_get(kDbgGfSegRows));
             return seg;
         };
-        const int seg_rows1 = pick_seg(strips1, 960, h);
-        const int seg_rows3 = pick_seg(strips3, 1024, std::max(6 * (2 * radius + 1), 512));
-        for (int it = 0; it < iterations; it++) {
-            const uint8_t *s0 = (it == 0 ? src : (const uint8_t *)dst) + (size_t)i0 * npx * src_cn;
-            const dim3 ga3(strips3, ceil_div(h, seg_rows3), m), ga1(strips1, ceil_div(h, seg_rows1), m);
+        P.seg_rows1 = pick_seg(strips1, 960, h);
+        P.seg_rows3 = pick_seg(strips3, 1024, std::max(6 * (2 * radius + 1), 512));
+    };
+    // the part's grey probe (flags zeroed by the caller's stream before the fork); with the
+    // one-byte hand-off it also leaves every image's channel 0 in cmp for the first pass
+    auto part_probe = [&](const Part &P) {
+        if (colour_all != nullptr)
+            hipLaunchKernelGGL(gf_grey_probe_kernel, dim3(probe_blocks, P.m), dim3(256), 0, P.st,
+                               src + (size_t)P.i0 * npx * 3, colour_all + P.i0, npx, P.cmp);
+    };
+    auto part_stage1 = [&](const Part &P, int it) {
+        hipStream_t st = P.st;
+        const int m = P.m, seg_rows1 = P.seg_rows1, seg_rows3 = P.seg_rows3;
+        const int *colour = P.colour;
+        float *ab = P.ab, *gs = P.gs;
+        const uint8_t *g0 = P.g0, *cmp = P.cmp;
+        const uint8_t *s0 = (it == 0 ? src : (const uint8_t *)dst) + (size_t)P.i0 * npx * src_cn;
+        const dim3 ga3(strips3, ceil_div(h, seg_rows3), m), ga1(strips1, ceil_div(h, seg_rows1), m);
 #define RF_GF_STAGE1(MODE)                                                                         \
     do {                                                                                           \
         if (src_cn == 3) {                                                                         \
-            hipLaunchKernelGGL((gf_stage1_kernel<3, 3, MODE>), ga3, dim3(stage1_threads(3)), 0, st, \
+            hipLaunchKernelGGL((gf_stage1_kernel<3, 3, MODE>), ga3, dim3(stage1_threads(3)), pad3, st, \
                                g0, s0, ab, h, w, radius, eps_f, eps_small, seg_rows3, colour, gs, 3); \
             if (cmp != nullptr)                                                                    \
-                hipLaunchKernelGGL((gf_stage1_kernel<1, 1, MODE>), ga1, dim3(stage1_threads(1)), 0, \
+                hipLaunchKernelGGL((gf_stage1_kernel<1, 1, MODE>), ga1, dim3(stage1_threads(1)), pad1, \
                                    st, g0, cmp, ab, h, w, radius, eps_f, eps_small, seg_rows1,      \
                                    colour, gs, 3);                                                 \
             else                                                                                   \
-                hipLaunchKernelGGL((gf_stage1_kernel<1, 3, MODE>), ga1, dim3(stage1_threads(1)), 0, \
+                hipLaunchKernelGGL((gf_stage1_kernel<1, 3, MODE>), ga1, dim3(stage1_threads(1)), pad1, \
                                    st, g0, s0, ab, h, w, radius, eps_f, eps_small, seg_rows1,       \
                                    colour, gs, 3);                                                 \
         } else {                                                                                   \
-            hipLaunchKernelGGL((gf_stage1_kernel<1, 1, MODE>), ga1, dim3(stage1_threads(1)), 0, st, \
+            hipLaunchKernelGGL((gf_stage1_kernel<1, 1, MODE>), ga1, dim3(stage1_threads(1)), pad1, st, \
                                g0, s0, ab, h, w, radius, eps_f, eps_small, seg_rows1, colour, gs, 1); \
         }                                                                                          \
     } while (0)
-            if (debug_get(kDbgGfExpSkip) & 1)
-                ;  // timing experiment: no stage 1 (results wrong)
-            else if (!keep_gs)
-                RF_GF_STAGE1(kS1Full);
-            else if (it == 0)
-                RF_GF_STAGE1(kS1Keep);
-            else
-                RF_GF_STAGE1(kS1Reuse);
+        if (debug_get(kDbgGfExpSkip) & 1)
+            ;  // timing experiment: no stage 1 (results wrong)
+        else if (!keep_gs)
+            RF_GF_STAGE1(kS1Full);
+        else if (it == 0)
+            RF_GF_STAGE1(kS1Keep);
+        else
+            RF_GF_STAGE1(kS1Reuse);
 #undef RF_GF_STAGE1
-            const int row_blocks = ceil_div(h, kBRows);
-            if (fused) {
-                const GfFusedArgs fa = {ab, rows, g0, d0, m, h, w, nb, src_cn, colour, st, xc,
-                                        debug_get(kDbgGfExpSkip),
-                                        it + 1 < iterations ? cmp : nullptr};
-                fused_launch(fa);
-                continue;
-            }
-            hipLaunchKernelGGL(gf_rowsum_kernel<4>, dim3((unsigned)(m * np * row_blocks)), dim3(64), 0,
-                               st, ab, rows, h, w, radius, row_blocks, np, colour, np);
-            dim3 gc(ceil_div(w, 64), 1, m);
-            if (src_cn == 3) {
-                hipLaunchKernelGGL((gf_colsum_apply_kernel<3, 3>), gc, dim3(64, 12), 0, st, rows,
-                                   g0, d0, h, w, radius, colour);
-                hipLaunchKernelGGL((gf_colsum_apply_kernel<1, 3>), gc, dim3(64, 4), 0, st, rows,
-                                   g0, d0, h, w, radius, colour);
-            } else {
-                hipLaunchKernelGGL((gf_colsum_apply_kernel<1, 1>), gc, dim3(64, 4), 0, st, rows,
-                                   g0, d0, h, w, radius, colour);
-            }
+    };
+    auto part_stage2 = [&](const Part &P, int it) {
+        hipStream_t st = P.st;
+        const int m = P.m;
+        if (fused) {
+            const GfFusedArgs fa = {P.ab, P.rows, P.g0, P.d0, m, h, w, nb, src_cn, P.colour, st, P.xc,
+                                    debug_get(kDbgGfExpSkip),
+                                    it + 1 < iterations ? P.cmp : nullptr};
+            fused_launch(fa);
+            return;
+        }
+        const int row_blocks = ceil_div(h, kBRows);
+        hipLaunchKernelGGL(gf_rowsum_kernel<4>, dim3((unsigned)(m * np * row_blocks)), dim3(64), 0,
+                           st, P.ab, P.rows, h, w, radius, row_blocks, np, P.colour, np);
+        dim3 gc(ceil_div(w, 64), 1, m);
+        if (src_cn == 3) {
+            hipLaunchKernelGGL((gf_colsum_apply_kernel<3, 3>), gc, dim3(64, 12), 0, st, P.rows,
+                               P.g0, P.d0, h, w, radius, P.colour);
+            hipLaunchKernelGGL((gf_colsum_apply_kernel<1, 3>), gc, dim3(64, 4), 0, st, P.rows,
+                               P.g0, P.d0, h, w, radius, P.colour);
+        } else {
+            hipLaunchKernelGGL((gf_colsum_apply_kernel<1, 1>), gc, dim3(64, 4), 0, st, P.rows,
+                               P.g0, P.d0, h, w, radius, P.colour);
+        }
+    };
+    auto run_part = [&](int i0, int m, int m_fill, char *ws, hipStream_t st) {
+        Part P{};
+        P.i0 = i0, P.m = m, P.ws = ws, P.st = st;
+        part_setup(P, m_fill);
+        part_probe(P);
+        for (int it = 0; it < iterations; it++) {
+            part_stage1(P, it);
+            part_stage2(P, it);
         }
     };
 
-    // A chunk of eight or more images runs as two halves on two streams - the caller's and a side
+    // A chunk of eight or more images runs as parts on two streams - the caller's and a side
     // stream of the library, forked and joined with events, so the call still looks stream-ordered
     // to the caller and can be captured into a graph.  The kernels of a pass are bound by different
     // things (stage 1: the issue rate of its 4-cycle VALU instructions; row states: the latency of
-    // a chunk of loads; column walk: memory bandwidth), and every launch ends in a tail of partly
-    // filled CUs: the other half's kernels fill both.  The debug option "gf_one_stream" keeps
-    // everything on the caller's stream, "gf_force_two_streams" forks from two images on
-    // (cross-checks; identical bytes).
+    // a chunk of loads; column walk: memory bandwidth).
+    //   aligned schedule (debug option "gf_stagger" = 0): two halves, each running its passes on its
+    //       own stream from the same instant: both are in stage 1 together, then both in the walks -
+    //       the second stream fills launch tails, nothing else.
+    //   staggered schedule ("gf_stagger" = 1): the stage-1 launches of the parts are chained by
+    //       events in the order (pass, part), parts alternating between the streams, so that at any
+    //       time one part is in its VALU-bound stage 1 and the other stream's part in its
+    //       memory-bound walks.  Events only: stream-ordered for the caller, capturable.
+    // The debug option "gf_one_stream" keeps everything on the caller's stream,
+    // "gf_force_two_streams" forks from two images on (cross-checks; identical bytes).
     char *ws0 = static_cast<char *>(workspace) + header;
     hipStream_t side = nullptr;
     // (tools/gf_stream_sweep.py, 3 passes at 4K, two streams over one: grey 1.10 / 1.18 / 1.00 /
@@ -1246,31 +1312,73 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
         hipStream_t s;
         ~SideHold() { gf_side_release(s); }
     } side_hold{side};
+    struct Events {  // destroyed on every path out (a pending event is released on completion)
+        std::vector<hipEvent_t> ev;
+        hipEvent_t make()
+        {
+            hipEvent_t e = nullptr;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess)
+                return nullptr;
+            ev.push_back(e);
+            return e;
+        }
+        ~Events()
+        {
+            for (hipEvent_t e : ev)
+                (void)hipEventDestroy(e);
+        }
+    };
+    const int stagger = debug_get(kDbgGfStagger);
     for (int i0 = 0; i0 < n; i0 += chunk) {
         const int m = std::min(chunk, n - i0);
         if (side == nullptr || m < fork_from) {
             run_part(i0, m, m, ws0, stream);
             continue;
         }
-        const int ma = (m + 1) / 2;
-        struct Events {  // destroyed on every path out (a pending event is released on completion)
-            hipEvent_t fork = nullptr, join = nullptr;
-            ~Events()
-            {
-                if (fork)
-                    (void)hipEventDestroy(fork);
-                if (join)
-                    (void)hipEventDestroy(join);
+        Events evs;
+        hipEvent_t fork = evs.make(), join = evs.make();
+        if (!fork || !join)
+            return fail(RF_E_HIP, "rf_gf_u8: hipEventCreate failed");
+        RF_HIP_CHECK(hipEventRecord(fork, stream));
+        RF_HIP_CHECK(hipStreamWaitEvent(side, fork, 0));
+        if (!stagger) {
+            const int ma = (m + 1) / 2;
+            run_part(i0, ma, m, ws0, stream);
+            run_part(i0 + ma, m - ma, m, ws0 + (size_t)ma * per_img_used, side);
+        } else {
+            // parts alternate between the two streams; stage 1 of (pass, part) waits for stage 1 of
+            // its predecessor in that order, which runs on the other stream
+            int nparts = debug_get(kDbgGfParts) > 0 ? debug_get(kDbgGfParts) : 2;
+            nparts = std::max(2, std::min(std::min(nparts, 16), m)) & ~1;
+            std::vector<Part> parts((size_t)nparts);
+            int at = 0;
+            for (int p = 0; p < nparts; p++) {
+                Part &P = parts[(size_t)p];
+                P = Part{};
+                P.i0 = i0 + at;
+                P.m = m / nparts + (p < m % nparts ? 1 : 0);
+                P.ws = ws0 + (size_t)at * per_img_used;
+                P.st = (p & 1) ? side : stream;
+                at += P.m;
+                part_setup(P, P.m);
+                part_probe(P);
             }
-        } ev;
-        RF_HIP_CHECK(hipEventCreateWithFlags(&ev.fork, hipEventDisableTiming));
-        RF_HIP_CHECK(hipEventCreateWithFlags(&ev.join, hipEventDisableTiming));
-        RF_HIP_CHECK(hipEventRecord(ev.fork, stream));
-        RF_HIP_CHECK(hipStreamWaitEvent(side, ev.fork, 0));
-        run_part(i0, ma, m, ws0, stream);
-        run_part(i0 + ma, m - ma, m, ws0 + (size_t)ma * per_img_used, side);
-        RF_HIP_CHECK(hipEventRecord(ev.join, side));
-        RF_HIP_CHECK(hipStreamWaitEvent(stream, ev.join, 0));
+            hipEvent_t prev = nullptr;
+            for (int it = 0; it < iterations; it++)
+                for (int p = 0; p < nparts; p++) {
+                    const Part &P = parts[(size_t)p];
+                    if (prev != nullptr)
+                        RF_HIP_CHECK(hipStreamWaitEvent(P.st, prev, 0));
+                    part_stage1(P, it);
+                    prev = evs.make();
+                    if (!prev)
+                        return fail(RF_E_HIP, "rf_gf_u8: hipEventCreate failed");
+                    RF_HIP_CHECK(hipEventRecord(prev, P.st));
+                    part_stage2(P, it);
+                }
+        }
+        RF_HIP_CHECK(hipEventRecord(join, side));
+        RF_HIP_CHECK(hipStreamWaitEvent(stream, join, 0));
     }
     RF_HIP_CHECK(hipGetLastError());
     return RF_OK;

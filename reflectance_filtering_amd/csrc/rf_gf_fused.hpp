@@ -350,8 +350,10 @@ struct alignas(16) WalkLds {
 //     neighbouring blocks' misaligned 256-byte operand runs share - and the leaving operands, which
 //     are the entering operands of the blocks 5 and 6 places to the left - are no longer found in
 //     the XCD's L2, which the lock-step walk of the row-walk form gets for free.
-//   * Polls are bounded: a consumer whose words never arrive sets xc.sync[8] and goes on with what
-//     it has (wrong bytes instead of a hung device); tests read the word.
+//   * Polls are bounded: a consumer whose words never arrive goes on with what it has (wrong bytes
+//     instead of a hung device) and ORs 1 into xc.sync[8].  Nothing reads or clears that word - the
+//     form is an experiment behind a debug switch, and the byte comparison of
+//     test_gf_switches_keep_the_bytes is what would notice a stalled hand-off.
 // sub-tile slots per block of the chained hand-off, and the bytes of one image's hand-off buffer
 __host__ __device__ inline int gf_chain_nsub(int h, int radius)
 {

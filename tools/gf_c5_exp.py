@@ -39,12 +39,19 @@ def main():
     ap.add_argument("--src", choices=("grey", "colour"), default="grey")
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--lib", default=None,
+                    help="A/B timing: load THIS build of librf_hip.so instead of the package's own")
     ap.add_argument("settings", nargs="*", default=["base"])
     args = ap.parse_args()
     import torch
     import bench
     import reflectance_filtering_amd as rf
     from reflectance_filtering_amd import _ffi
+    if args.lib:
+        _ffi.LIB_PATH = os.path.abspath(args.lib)
+        sys.stderr.write("gf_c5_exp: loading %s instead of the package's library\n" % _ffi.LIB_PATH)
+        if _ffi.load_library().rf_version() & 0x3fffffff < 100:
+            raise SystemExit("gf_c5_exp: %s is not a librf_hip.so" % _ffi.LIB_PATH)
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     n, h, w = args.batch, 2160, 3840
