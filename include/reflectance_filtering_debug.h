@@ -36,6 +36,16 @@
  *                        (tools/jbf_tune.py --stage-only, timing only)
  *   "gf_exp_skip"        guided filter, TIMING ONLY, WRONG RESULTS: bit 0 no stage 1, bit 1 no row
  *                        walk, bit 2 no column walk (tools/gf_c5_exp.py)
+ *   "gf_stagger"         guided filter: staggered two-stream schedule - the stage-1 launches of the
+ *                        parts of a chunk are chained by events in (pass, part) order, parts alternating
+ *                        between the caller's stream and the side stream, so that one part's stage 1
+ *                        always faces the other's walks; identical bytes, measured no faster than the
+ *                        default (profiles/r05_c5_overlap.md), off by default
+ *   "gf_parts"           ... parts per chunk in that schedule (even, 2..16; 0 = 2)
+ *   "gf_s1_cap"          guided filter: stage-1 workgroups per CU (1..3, by a dynamic-LDS pad; 0 =
+ *                        whatever fits); identical bytes
+ *   "gf_s1_min_wgs"      guided filter: workgroups a stage-1 launch should at least have (chooses the
+ *                        rows per segment; 0 = chosen by the library); identical bytes
  */
 #ifndef REFLECTANCE_FILTERING_DEBUG_H
 #define REFLECTANCE_FILTERING_DEBUG_H

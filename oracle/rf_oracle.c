@@ -858,6 +858,12 @@ int rfo_gf_f32(const float *guide, const float *src, float *dst, int h, int w, i
     return gf_core(guide, src, NULL, dst, h, w, src_cn, radius, eps, threads);
 }
 
+/* The census form of the box mean alone (tests/test_oracle.py); counters through rfo_census. */
+void rfo_box_census_f32(const float *src, float *dst, int h, int w, int r)
+{
+    rfo_box_mean_census(src, dst, h, w, r);
+}
+
 /* Exposed for unit tests of the box mean alone. */
 void rfo_box_mean_f32(const float *src, float *dst, int h, int w, int r)
 {

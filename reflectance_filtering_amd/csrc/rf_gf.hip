@@ -61,27 +61,32 @@ template <int SCN, bool GUIDE = true>
 struct Quant {
     static constexpr int G0 = GUIDE ? 9 : 0;  // first src quantity
     static constexpr int NQ = G0 + 4 * SCN;
-    __device__ static inline void eval(const uint8_t *g, const uint8_t *p, uint32_t *v)
+    // acc[q] += (NEG ? -1 : +1) * quantity q of the pixel with guide bytes g0..g2 and src bytes p[]
+    // (uint32 wrap-around is exact).  A row that leaves the window is added with one factor of
+    // every product negated: one v_mad_i32_i24 per product either way, instead of a multiply and
+    // a subtract.
+    template <bool NEG>
+    __device__ static inline void accumulate(int g0, int g1, int g2, const int *p, uint32_t *acc)
     {
-        const uint32_t g0 = g[0], g1 = g[1], g2 = g[2];
+        const int s0 = NEG ? -g0 : g0, s1 = NEG ? -g1 : g1, s2 = NEG ? -g2 : g2;
         if (GUIDE) {
-            v[0] = g0;
-            v[1] = g1;
-            v[2] = g2;
-            v[3] = g0 * g0;
-            v[4] = g0 * g1;
-            v[5] = g0 * g2;
-            v[6] = g1 * g1;
-            v[7] = g1 * g2;
-            v[8] = g2 * g2;
+            acc[0] += (uint32_t)s0;
+            acc[1] += (uint32_t)s1;
+            acc[2] += (uint32_t)s2;
+            acc[3] += (uint32_t)(s0 * g0);
+            acc[4] += (uint32_t)(s0 * g1);
+            acc[5] += (uint32_t)(s0 * g2);
+            acc[6] += (uint32_t)(s1 * g1);
+            acc[7] += (uint32_t)(s1 * g2);
+            acc[8] += (uint32_t)(s2 * g2);
         }
 #pragma unroll
         for (int s = 0; s < SCN; s++) {
-            const uint32_t ps = p[s];
-            v[G0 + s] = ps;
-            v[G0 + SCN + 3 * s + 0] = ps * g0;
-            v[G0 + SCN + 3 * s + 1] = ps * g1;
-            v[G0 + SCN + 3 * s + 2] = ps * g2;
+            const int ps = NEG ? -p[s] : p[s];
+            acc[G0 + s] += (uint32_t)ps;
+            acc[G0 + SCN + 3 * s + 0] += (uint32_t)(ps * g0);
+            acc[G0 + SCN + 3 * s + 1] += (uint32_t)(ps * g1);
+            acc[G0 + SCN + 3 * s + 2] += (uint32_t)(ps * g2);
         }
     }
 };
@@ -288,6 +293,19 @@ __global__ __launch_bounds__(256) void gf_grey_probe_kernel(const uint8_t *__res
 //   kS1Reuse   only the 4*SCN src quantities are box-summed; the guide half is read from gs
 //              (requested at the top of a row, used at its end)          - later passes
 enum { kS1Full = 0, kS1Keep = 1, kS1Reuse = 2 };
+// Diagnostic build only (-DRF_GF_S1_STAMP, tools/gf_s1_stamp.py): shader cycles per phase of the row
+// loop, summed over waves, in a buffer of their own; no output depends on them.
+#ifdef RF_GF_S1_STAMP
+__device__ unsigned long long g_s1_stamps[16];
+#define RF_S1_STAMP(i)                                                  \
+    do {                                                                \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();   \
+        st_acc[i] += now_ - st_t;                                       \
+        st_t = now_;                                                    \
+    } while (0)
+#else
+#define RF_S1_STAMP(i) do { } while (0)
+#endif
 template <int SCN, int SPX, int MODE>
 __global__ __launch_bounds__(stage1_threads(SCN)) void gf_stage1_kernel(
     const uint8_t *__restrict__ guide, const uint8_t *__restrict__ src, float *__restrict__ ab,
@@ -321,10 +339,16 @@ __global__ __launch_bounds__(stage1_threads(SCN)) void gf_stage1_kernel(
     const double scale = 1.0 / (double)(ks * ks);
     const double nbias = -(4503599627370496.0 * scale);
 
-    int gx[kACols];
+    // byte offsets of the thread's columns within an image row (guide: 3 bytes per pixel, src: SPX);
+    // a row's bytes are then (wave-uniform row pointer) + (32-bit lane offset): no 64-bit vector
+    // arithmetic per load
+    uint32_t gx3[kACols], gxs[kACols];
 #pragma unroll
-    for (int k = 0; k < kACols; k++)
-        gx[k] = border_interpolate(xs - radius + tid * kACols + k, w, RF_BORDER_REFLECT);
+    for (int k = 0; k < kACols; k++) {
+        const int gx = border_interpolate(xs - radius + tid * kACols + k, w, RF_BORDER_REFLECT);
+        gx3[k] = (uint32_t)gx * 3u;
+        gxs[k] = (uint32_t)gx * (uint32_t)SPX;
+    }
 
     uint32_t V[kACols][NQ];
 #pragma unroll
@@ -336,21 +360,32 @@ __global__ __launch_bounds__(stage1_threads(SCN)) void gf_stage1_kernel(
     // (Byte loads, 3 x (3 + SCN) per row step and thread, are not what limits this kernel: fetching
     // a thread's three pixels as one 12-byte load and picking the bytes apart was measured 10 %
     // SLOWER - the extra VALU work costs more than the vector-memory instructions it saves.)
-    auto add_row = [&](int yy, bool add) {
+    // One image row of the strip enters (or leaves) the vertical running sums.  The row's bytes are
+    // read through a buffer descriptor over that row (wave-uniform base: scalar arithmetic only)
+    // with the lane's constant 32-bit byte offset: no vector address arithmetic per load.
+    auto add_row = [&](int yy, auto neg_c) __attribute__((always_inline)) {
+        constexpr bool NEG = decltype(neg_c)::value;
         const int gy = border_interpolate(yy, h, RF_BORDER_REFLECT);
+        const auto rg = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint8_t *>(gimg + (size_t)gy * w * 3), 0, w * 3, 0x00020000);
+        const auto rp = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint8_t *>(simg + (size_t)gy * w * SPX), 0, w * SPX, 0x00020000);
 #pragma unroll
         for (int k = 0; k < kACols; k++) {
-            uint32_t v[NQ];
-            const size_t pix = (size_t)gy * w + gx[k];
-            Q::eval(gimg + pix * 3, simg + pix * SPX, v);
+            const uint32_t g01 = __builtin_amdgcn_raw_buffer_load_b16(rg, (int)gx3[k], 0, 0);
+            const int g2 = __builtin_amdgcn_raw_buffer_load_b8(rg, (int)gx3[k] + 2, 0, 0);
+            int p[SCN];
 #pragma unroll
-            for (int q = 0; q < NQ; q++)
-                V[k][q] = add ? V[k][q] + v[q] : V[k][q] - v[q];
+            for (int sc = 0; sc < SCN; sc++)
+                p[sc] = __builtin_amdgcn_raw_buffer_load_b8(rp, (int)gxs[k] + sc, 0, 0);
+            Q::template accumulate<NEG>((int)(g01 & 0xffu), (int)(g01 >> 8), g2, p, V[k]);
         }
     };
+    using RowIn = std::integral_constant<bool, false>;
+    using RowOut = std::integral_constant<bool, true>;
 
     for (int yy = ys - radius; yy < ys + radius; yy++)
-        add_row(yy, true);
+        add_row(yy, RowIn{});
     if (tid == 0)
 #pragma unroll
         for (int q = 0; q < NQ; q++)
@@ -378,6 +413,11 @@ __global__ __launch_bounds__(stage1_threads(SCN)) void gf_stage1_kernel(
         col_ok[k] = !(c < radius || c >= kACW - radius || xs - radius + c >= w);
         all_ok = all_ok && col_ok[k];
     }
+#ifdef RF_GF_S1_STAMP
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_t = __builtin_amdgcn_s_memtime();
+    unsigned long long st_n = 0;
+#endif
     for (int y = ys; y < ye; y++) {
         // later passes: the guide records of the row's pixels, used after the barriers
         // (gs: [img][row][kGsFloats][w] - the floats of a record are w apart, so the lanes of a wave
@@ -406,7 +446,8 @@ __global__ __launch_bounds__(stage1_threads(SCN)) void gf_stage1_kernel(
                 }
             }
         }
-        add_row(y + radius, true);
+        add_row(y + radius, RowIn{});
+        RF_S1_STAMP(0);
         // inclusive prefix over the strip's columns, per quantity.  The six DPP steps of the wave
         // scan run stage by stage across the quantities: back to back on one quantity every step
         // waits out the VALU-write -> DPP-read hazard (an s_nop per step and quantity)
@@ -436,6 +477,7 @@ __global__ __launch_bounds__(stage1_threads(SCN)) void gf_stage1_kernel(
         for (int q = 0; q < NQ; q++)
             asm volatile("v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
                          : "+v"(incl[q]));
+        RF_S1_STAMP(7);
         {
             // lanes 0 .. kAWaves-2-wave add the wave total (lane 63's prefix) to the entries of the
             // waves to the right
@@ -447,7 +489,9 @@ __global__ __launch_bounds__(stage1_threads(SCN)) void gf_stage1_kernel(
                     atomicAdd(&wave_acc[q][dstw], tot);
             }
         }
+        RF_S1_STAMP(1);
         __syncthreads();
+        RF_S1_STAMP(2);
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
             const uint32_t acc = wave_acc[q][wave];
@@ -460,7 +504,9 @@ __global__ __launch_bounds__(stage1_threads(SCN)) void gf_stage1_kernel(
                 pk -= V[k][q];
             }
         }
+        RF_S1_STAMP(3);
         __syncthreads();
+        RF_S1_STAMP(4);
 #pragma unroll
         for (int k = 0; k < kACols; k++) {
             const int c = tid * kACols + k;
@@ -471,7 +517,6 @@ __global__ __launch_bounds__(stage1_threads(SCN)) void gf_stage1_kernel(
 #pragma unroll
             for (int q = 0; q < NQ; q++)
                 m[q] = mean_of(pfx[q][c + radius + 1] - pfx[q][c - radius], scale, nbias);
-            const size_t pix = (size_t)y * w + x;
             float ab_px[4 * SCN];
             if (MODE == kS1Reuse) {
                 gf_src_algebra<SCN>(gsr[k], m, ab_px);
@@ -488,13 +533,31 @@ __global__ __launch_bounds__(stage1_threads(SCN)) void gf_stage1_kernel(
             }
             // the four planes of a src channel (alpha_0..2, beta) interleaved per pixel: one
             // 16-byte store, and stage 2 reads 256-byte runs per image row instead of 64-byte ones
+            // (through a descriptor over the image row: wave-uniform base, the lane's constant offset)
 #pragma unroll
-            for (int sc = 0; sc < SCN; sc++)
-                *reinterpret_cast<float4 *>(abimg + ((size_t)sc * npx + pix) * 4) =
-                    make_float4(ab_px[4 * sc], ab_px[4 * sc + 1], ab_px[4 * sc + 2], ab_px[4 * sc + 3]);
+            for (int sc = 0; sc < SCN; sc++) {
+                const auto rab = __builtin_amdgcn_make_buffer_rsrc(
+                    abimg + ((size_t)sc * npx + (size_t)y * w) * 4, 0, w * 16, 0x00020000);
+                typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+                const u32x4_t o = {__float_as_uint(ab_px[4 * sc]), __float_as_uint(ab_px[4 * sc + 1]),
+                                   __float_as_uint(ab_px[4 * sc + 2]), __float_as_uint(ab_px[4 * sc + 3])};
+                __builtin_amdgcn_raw_buffer_store_b128(o, rab, x * 16, 0, 0);
+            }
         }
-        add_row(y - radius, false);
+        RF_S1_STAMP(5);
+        add_row(y - radius, RowOut{});
+        RF_S1_STAMP(6);
+#ifdef RF_GF_S1_STAMP
+        st_n++;
+#endif
     }
+#ifdef RF_GF_S1_STAMP
+    if (lane == 0) {
+        for (int i = 0; i < 8; i++)
+            atomicAdd(&g_s1_stamps[i], st_acc[i]);
+        atomicAdd(&g_s1_stamps[15], st_n);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -944,6 +1007,18 @@ size_t gf_per_img_chained(size_t npx, int np, int nb, int h, int radius)
 }
 }  // namespace rf
 
+#ifdef RF_GF_S1_STAMP
+extern "C" int rf_debug_gf_s1_stamps(unsigned long long *out16)
+{
+    unsigned long long zero[16] = {};
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(rf::g_s1_stamps), sizeof(zero)) != hipSuccess)
+        return -4;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(rf::g_s1_stamps), zero, sizeof(zero)) != hipSuccess)
+        return -4;
+    return 0;
+}
+#endif
+
 extern "C" size_t rf_gf_workspace_bytes(int n, int h, int w, int guide_cn, int src_cn, int radius)
 {
     (void)guide_cn;
@@ -991,6 +1066,8 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
         return fail(RF_E_UNSUPPORTED, "rf_gf_u8: src channels must be 1 or 3 (got %d)", src_cn);
     if (radius < 0 || radius > 4096)
         return fail(RF_E_UNSUPPORTED, "rf_gf_u8: radius %d outside 0..4096", radius);
+    if (w >= (1 << 27))  // the kernels address a row's alpha/beta (16 B per pixel) with 32-bit offsets
+        return fail(RF_E_UNSUPPORTED, "rf_gf_u8: width %d beyond 2^27 - 1", w);
     {
         const size_t px = (size_t)n * h * w;
         if (ranges_overlap(dst, px * src_cn, guide, px * 3))

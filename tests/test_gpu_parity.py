@@ -925,8 +925,13 @@ def test_gf_switches_keep_the_bytes(env, radius, eps):
     assert np.array_equal(want[1].cpu().numpy(),
                           co.guided_filter(guides[1], co.guided_filter(guides[1], co.guided_filter(
                               guides[1], srcs[1], radius, eps), radius, eps), radius, eps))
+    # (round 5: the staggered two-stream schedule - stage 1 of one part chained behind stage 1 of the
+    #  other by events - in 2 and 4 parts, stage 1 capped at 2 / 3 workgroups per CU, other segment counts)
     for opts in ({"gf_chained": 1}, {"gf_no_compact": 1}, {"gf_one_stream": 1},
-                 {"gf_chained": 1, "gf_no_compact": 1, "gf_force_two_streams": 1}):
+                 {"gf_chained": 1, "gf_no_compact": 1, "gf_force_two_streams": 1},
+                 {"gf_stagger": 1}, {"gf_stagger": 1, "gf_parts": 4, "gf_s1_cap": 2},
+                 {"gf_stagger": 1, "gf_force_two_streams": 1, "gf_parts": 6, "gf_s1_min_wgs": 64},
+                 {"gf_s1_cap": 3, "gf_s1_min_wgs": 4096}):
         with rf._ffi.debug_options(**opts):
             got = rf.ops.guided_filter_u8(g, s, radius, eps, iterations=3)
         assert torch.equal(got, want), opts

@@ -219,3 +219,42 @@ def test_box_mean_against_scipy_uniform_filter():
         want = ndi.uniform_filter(plane.astype(np.float64), size=2 * r + 1, mode="reflect")
         got = co.box_mean_f32(plane, r)
         assert np.abs(got - want).max() < 1e-3 * max(1.0, np.abs(want).max()) * 1e-1, (h, w, r)
+
+
+def test_box_census_counts_rounded_operations():
+    """The exactness census (rfo_census, tools/gf_exactness.py) leaves the filter's bytes alone, finds no
+    rounded operation on smooth data, and does find them when one alpha/beta-like plane mixes
+    magnitudes 2^60 apart (a double cannot hold both in one sum)."""
+    import ctypes
+    from tests import synth
+    L = co.lib()
+    L.rfo_census.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_ulonglong)]
+    L.rfo_census.restype = None
+    h, w, r = 60, 83, 7
+    guide = synth.flat_guide_u8(h, w, seed=3, cells=9)
+    src = synth.reflectance_like_u8(h, w, seed=4)[:, :, :1].copy()
+    want = co.guided_filter(guide, src, r, 3.0)
+    buf = (ctypes.c_ulonglong * 16)()
+    L.rfo_census(1, None)
+    try:
+        got = co.guided_filter(guide, src, r, 3.0)
+    finally:
+        L.rfo_census(0, buf)
+    assert np.array_equal(got, want)
+    rows, rows_bad, row_ops, row_ops_bad, cols, cols_bad, col_ops, col_ops_bad, ok_rows, planes = buf[:10]
+    assert planes == 4 and rows == 4 * h and cols == 4 * w
+    assert row_ops == 4 * h * (2 * r + 1 + 2 * (w - 1)) and col_ops == 4 * w * (2 * r + 2 * h)
+    assert rows_bad == 0 and row_ops_bad == 0 and ok_rows <= rows
+    # the instrument itself: TwoSum flags a sum whose addends do not fit one double
+    L.rfo_box_census_f32 = getattr(L, "rfo_box_census_f32")
+    L.rfo_box_census_f32.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
+                                     ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    plane = np.full((12, 40), 1.0, np.float32)
+    plane[5, 20] = np.float32(2.0 ** -60)
+    out = np.empty_like(plane)
+    L.rfo_census(1, None)
+    L.rfo_box_census_f32(plane.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                         out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), 12, 40, 3)
+    L.rfo_census(0, buf)
+    assert np.array_equal(out, co.box_mean_f32(plane, 3))
+    assert buf[1] == 1 and buf[3] > 0 and buf[8] == 11        # one row rounds, and fails the test

@@ -93,3 +93,32 @@ def test_t2_report_identifies_a_non_default_variant(tmp_path, monkeypatch):
     assert ["jbf_true_division"] in vs["jbf"]["identified"]
     assert not vs["jbf"]["default_is_exact"]
     assert all("jbf_true_division" in c for c in vs["jbf"]["identified"])
+
+
+def test_gf_overlap_table_from_a_kernel_trace(tmp_path, capsys):
+    """tools/gf_overlap.py on a hand-made rocprofv3 kernel trace: stage 1 of queue 1 runs 10 us, a row
+    walk of queue 2 covers its second half, a column walk of its OWN queue does not count."""
+    hdr = ('"Kind","Agent_Id","Queue_Id","Stream_Id","Thread_Id","Dispatch_Id","Kernel_Id","Kernel_Name",'
+           '"Correlation_Id","Start_Timestamp","End_Timestamp"\n')
+    rows = [(1, "void rf::(anonymous namespace)::gf_stage1_kernel<1, 1, 0>(unsigned char const*)", 1000000, 11000000),
+            (2, "void rf::gf_rowstate_kernel<45>(float const*)", 6000000, 13000000),
+            (1, "void rf::gf_colwalk_kernel<45, false>(float const*)", 11000000, 15000000),
+            (1, "void at::native::vectorized_elementwise_kernel<4>(int)", 0, 500)]
+    d = tmp_path / "trace"
+    d.mkdir()
+    with open(d / "t_kernel_trace.csv", "w") as fh:
+        fh.write(hdr)
+        for k, (q, name, t0, t1) in enumerate(rows):
+            fh.write('"KERNEL_DISPATCH","Agent 2",%d,%d,1,%d,1,"%s",%d,%d,%d\n' % (q, q - 1, k, name, k, t0, t1))
+    mod = _load("gf_overlap")
+    old = sys.argv
+    sys.argv = ["gf_overlap.py", str(d), "--label", "test", "--out", str(tmp_path / "o.md")]
+    try:
+        mod.main()
+    finally:
+        sys.argv = old
+    txt = capsys.readouterr().out
+    assert "| stage1 | 1 | 10.00 | 10.00 |" in txt
+    assert "| stage 1 and a walk kernel both running | 5.00 |" in txt
+    assert "| 0 | 1/0 | 0.00 | 10.00 | 50 % |" in txt
+    assert "**50 %**" in txt and (tmp_path / "o.md").read_text() == txt + "\n"

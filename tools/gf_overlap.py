@@ -95,7 +95,7 @@ def split_steps(rows, gap_ns):
     return steps
 
 
-def report(step, label):
+def report(step, label, brief=False):
     ms = 1e-6
     t0 = min(r["t0"] for r in step)
     t1 = max(r["t1"] for r in step)
@@ -129,20 +129,23 @@ def report(step, label):
         lines.append("| %s | %.2f | %.0f %% |" % (what, v * ms, 100.0 * v / span))
     lines.append("| any guided-filter kernel running | %.2f | %.0f %% |" % (length(anyk) * ms, 100.0 * length(anyk) / span))
     lines.append("")
-    lines.append("Per stage-1 launch (in start order): duration, and the share of it during which a row- or "
-                 "column-walk kernel of ANOTHER queue was running:")
-    lines.append("")
-    lines.append("| # | queue | start ms | duration ms | walk of another queue beside it |")
-    lines.append("|---|---|---|---|---|")
+    if not brief:
+        lines.append("Per stage-1 launch (in start order; launches of the instantiation that does not apply "
+                     "to the images exit at once and are left out): duration, and the share of it during which a "
+                     "row- or column-walk kernel of ANOTHER queue was running:")
+        lines.append("")
+        lines.append("| # | queue | start ms | duration ms | walk of another queue beside it |")
+        lines.append("|---|---|---|---|---|")
     fr = []
-    for k, r in enumerate([r for r in step if r["cls"] == "stage1"]):
+    for k, r in enumerate([r for r in step if r["cls"] == "stage1" and r["t1"] - r["t0"] > 300000]):
         other = union([(x["t0"], x["t1"]) for x in step
                        if x["cls"] in ("row walk", "column walk") and x["q"] != r["q"]])
         cov = length(intersect([[r["t0"], r["t1"]]], other))
         f = cov / float(max(1, r["t1"] - r["t0"]))
         fr.append((f, r["t1"] - r["t0"]))
-        lines.append("| %d | %s | %.2f | %.2f | %.0f %% |" % (k, "/".join(str(x) for x in r["q"]),
-                                                             (r["t0"] - t0) * ms, (r["t1"] - r["t0"]) * ms, 100 * f))
+        if not brief:
+            lines.append("| %d | %s | %.2f | %.2f | %.0f %% |" % (k, "/".join(str(x) for x in r["q"]),
+                                                                 (r["t0"] - t0) * ms, (r["t1"] - r["t0"]) * ms, 100 * f))
     if fr:
         tot = sum(d for _, d in fr)
         lines.append("")
@@ -156,14 +159,23 @@ def main():
     ap.add_argument("trace", help="a *_kernel_trace.csv or a directory that holds some")
     ap.add_argument("--label", default="schedule")
     ap.add_argument("--gap-ms", type=float, default=0.5)
+    ap.add_argument("--steps", type=int, default=0,
+                    help="the trace holds this many back-to-back steps (no idle gap between them): cut "
+                         "the launches, in start order, into that many equal runs instead of at gaps")
+    ap.add_argument("--brief", action="store_true", help="leave the per-launch table out")
     ap.add_argument("--out", default=None, help="append the table to this file")
     args = ap.parse_args()
     rows = load(args.trace)
     if not rows:
         sys.exit("gf_overlap: no guided-filter kernels in %s" % args.trace)
-    steps = split_steps(rows, args.gap_ms * 1e6)
+    if args.steps > 0:
+        per = len(rows) // args.steps
+        steps = [rows[k * per:(k + 1) * per] for k in range(args.steps)]
+    else:
+        steps = split_steps(rows, args.gap_ms * 1e6)
     steps = [s for s in steps if any(r["cls"] == "stage1" for r in s)]
-    txt = report(steps[-1], "%s (%d steps in the trace, the last one shown)" % (args.label, len(steps)))
+    txt = report(steps[-1], "%s (%d steps in the trace, the last one shown)" % (args.label, len(steps)),
+                 brief=args.brief)
     sys.stdout.write(txt)
     if args.out:
         with open(args.out, "a") as fh:
