@@ -1387,6 +1387,120 @@ __global__ __launch_bounds__(1024) void jbf_tile64_kernel(
     }
 }
 
+// One channel of a 3-channel result: the lane's 4 horizontally adjacent outputs of channel c.
+__device__ inline void store_quad_channel(uint8_t *dst, size_t img, int oy, int ox0, int h, int w,
+                                          int c, const float (&sum)[kPix][1],
+                                          const float (&wsum)[kPix], int flags)
+{
+    if (oy >= h || ox0 >= w)
+        return;
+    uint8_t *o = dst + (img + (size_t)oy * w + ox0) * 3 + c;
+#pragma unroll
+    for (int p = 0; p < kPix; p++) {
+        if (ox0 + p >= w)
+            break;
+        const float d = (flags & RF_JBF_TRUE_DIVISION) ? wsum[p] : __fdiv_rn(1.0f, wsum[p]);
+        o[p * 3] = saturate_u8(finish_value(sum[p][0], d, flags));
+    }
+}
+
+// Radius 53..68 (--sigma_spatial is a free float of the reference's tool,
+// /root/reference/filter_reflectance.py:117-119: sigma 36 -> radius 54, 40 -> 60): the 64x64 tile
+// with its halo no longer fits the LDS, so a workgroup covers its 64x64 outputs in 64/crows passes of
+// crows rows (32, 16 or 8: whatever the weight table of (r+1) rows leaves room for), each pass
+// staging (crows + 2r) rows of 4-byte texels {B,G,R joint, ONE src byte} at row pitch 208 and running
+// the grey asm tap loop on its first 16*crows threads.  A 3-channel src whose channels differ takes
+// three such passes per row band, one per channel - the weights are formed three times (78 instead
+// of 44 VALU instructions per column step), which is still an order of magnitude below the
+// one-thread-per-pixel kernel these radii fell to before.  Per-pixel tap order and arithmetic are
+// those of every other form: identical bytes.
+template <int GREP>
+__global__ __launch_bounds__(1024) void jbf_wide_kernel(
+    const uint8_t *__restrict__ joint, const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
+    int h, int w, int jcn, int scn, int radius, int border, const float *__restrict__ lut, int nz,
+    const int *__restrict__ hwtab, const float *__restrict__ swsym, int sw_len, int tiles_x,
+    int tiles_per_img, int flags, int crows)
+{
+    constexpr int NT = 1024, TLW = 208, Q4 = TLW / 4, QW = 16;
+    extern __shared__ __align__(16) unsigned char smem[];
+    int *flag_word = reinterpret_cast<int *>(smem);
+    float *swl = reinterpret_cast<float *>(smem + 16);
+    const int sw_bytes = ((radius + 1) * sw_len * 4 + 15) & ~15;
+    uint32_t *tile4 = reinterpret_cast<uint32_t *>(smem + 16 + sw_bytes);
+    const int tid = threadIdx.x;
+    if (tid == 0)
+        *flag_word = 3;
+    const int tile_id = xcd_contiguous_tile((int)blockIdx.x, (int)gridDim.x);
+    const int img_idx = tile_id / tiles_per_img;
+    const int t_in_img = tile_id - img_idx * tiles_per_img;
+    const int tile_y0 = (t_in_img / tiles_x) * 64;
+    const int tile_x0 = (t_in_img % tiles_x) * 64;
+    const size_t img = (size_t)img_idx * h * w;
+    const int r4 = (radius + 3) & ~3;
+    const int tx = tid % QW, ty = tid / QW;
+    for (int i = tid; i < (radius + 1) * sw_len; i += NT)
+        swl[i] = swsym[i];
+    // the LUT at the very end of the allocation: gathers past its last entry read 0 (probed)
+    float *lut_g = reinterpret_cast<float *>(smem + kT64Lds - nz * GREP * 4);
+    for (int i = tid; i < nz * GREP; i += NT)
+        lut_g[i] = lut[i / GREP];
+    const int tlh = crows + 2 * radius;
+    const uint32_t sw_addr0 = lds_addr(swl);
+    const uint32_t lut_lane_addr = lds_addr(lut_g) + (uint32_t)(tid & (GREP - 1)) * 4u;
+    const uint32_t tile_lane_addr = lds_addr(tile4) + (uint32_t)tx * 4u;
+    for (int y0 = tile_y0; y0 < tile_y0 + 64 && y0 < h; y0 += crows) {
+        int all_grey = scn == 1;
+        for (int c = 0; c < scn; c++) {
+            __syncthreads();  // everyone is done with the previous contents of the tile (and flag)
+            int grey = 1;
+            for (int item = tid; item < tlh * Q4; item += NT) {
+                const int ry = item / Q4, k = item - ry * Q4;
+                const int gy = border_interpolate(y0 - radius + ry, h, border);
+                uint32_t jv[4], sv[4];
+                load_tile_quad(joint, src, img, gy, tile_x0 - r4 + 4 * k, w, jcn, scn, border, jv, sv);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (c == 0 && scn == 3)
+                        grey &= (int)(((sv[u] ^ (sv[u] >> 8)) & 0xffffu) == 0u);
+                    tile4[ry * TLW + u * Q4 + k] = jv[u] | (((sv[u] >> (8 * c)) & 0xffu) << 24);
+                }
+            }
+            if (c == 0 && scn == 3) {
+                all_grey = block_all2(grey, 1, flag_word) & 1;  // (barrier inside)
+                __syncthreads();                                // everyone has read the word
+                if (tid == 0)
+                    *flag_word = 3;
+            } else {
+                __syncthreads();
+            }
+            if (tid < QW * crows) {
+                uint32_t jc[kPix];
+#pragma unroll
+                for (int p = 0; p < kPix; p++) {
+                    const int X = 4 * tx + p + r4;
+                    jc[p] = tile4[(ty + radius) * TLW + (X & 3) * Q4 + (X >> 2)] & 0x00ffffffu;
+                }
+                float sum1[kPix][1], wsum[kPix];
+#pragma unroll
+                for (int p = 0; p < kPix; p++) {
+                    sum1[p][0] = 0.f;
+                    wsum[p] = 0.f;
+                }
+                jbf_tap_loop_grey4<GREP, TLW>(lut_lane_addr, sw_addr0, tile_lane_addr, jc, ty, radius,
+                                              r4, sw_len, hwtab, sum1, wsum);
+                if (scn == 1)
+                    store_quad<1, 1>(dst, img, y0 + ty, tile_x0 + 4 * tx, h, w, sum1, wsum, flags);
+                else if (all_grey)
+                    store_quad<1, 3>(dst, img, y0 + ty, tile_x0 + 4 * tx, h, w, sum1, wsum, flags);
+                else
+                    store_quad_channel(dst, img, y0 + ty, tile_x0 + 4 * tx, h, w, c, sum1, wsum, flags);
+            }
+            if (all_grey)
+                break;
+        }
+    }
+}
+
 // Probe for the "LDS reads beyond the allocation return 0" behaviour the 64x64 kernel relies on.
 __global__ void lds_oob_probe_kernel(uint32_t *out)
 {
@@ -1575,6 +1689,36 @@ int launch_tile64_rows(const JbfTables &t, int nz, int crows, const uint8_t *joi
                                                         border, flags, stream, 0, h, cols_main, sx);
     }
     return rc;
+}
+
+// Radius 53..68: rows per pass of jbf_wide_kernel for a LUT replicated grep times (0: does not fit)
+int wide_fits(const JbfTables &t, int nz, int grep)
+{
+    if (2 * t.r4 + 64 + 8 > 208)
+        return 0;
+    const size_t sw_bytes = 16 + (((size_t)(t.radius + 1) * t.sw_len * 4 + 15) & ~(size_t)15);
+    for (int crows = 32; crows >= 8; crows >>= 1)
+        if (sw_bytes + (size_t)208 * (crows + 2 * t.radius) * 4 + (size_t)nz * grep * 4 <= (size_t)kT64Lds)
+            return crows;
+    return 0;
+}
+
+template <int GREP>
+int launch_wide(const JbfTables &t, int nz, int crows, const uint8_t *joint, const uint8_t *src,
+                uint8_t *dst, int n, int h, int w, int jcn, int scn, int border, int flags,
+                hipStream_t stream)
+{
+    const int tiles_x = ceil_div(w, 64), tiles_y = ceil_div(h, 64);
+    const long long blocks = (long long)tiles_x * tiles_y * n;
+    if (blocks > 0x7fffffffLL)
+        return fail(RF_E_UNSUPPORTED, "rf_jbf_u8: batch too large for one launch");
+    auto kern = jbf_wide_kernel<GREP>;
+    RF_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     kT64Lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(1024), kT64Lds, stream, joint, src, dst, h,
+                       w, jcn, scn, t.radius, border, t.d_lut, nz, t.d_hw, t.d_swsym, t.sw_len,
+                       tiles_x, tiles_x * tiles_y, flags, crows);
+    return RF_OK;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1911,7 +2055,7 @@ extern "C" int rf_jbf_u8(const uint8_t *joint, const uint8_t *src, uint8_t *dst,
     // src; the clamp-free 8x table is next
     // tune 7 forces the 64x64 kernel, tune 1..6 the 64xTH kernel
     bool done = false;
-    if (!(flags & RF_JBF_FORCE_GENERIC) && t.r4 <= 52 && (tune == 0 || tune == 7)) {
+    if (!(flags & RF_JBF_FORCE_GENERIC) && t.r4 <= 68 && (tune == 0 || tune == 7)) {
         bool oob_ok = false;
         rc = lds_oob_reads_zero(t.device, &oob_ok);
         if (rc != RF_OK)
@@ -1949,6 +2093,27 @@ extern "C" int rf_jbf_u8(const uint8_t *joint, const uint8_t *src, uint8_t *dst,
             RF_T64(16, 8, 176)
             RF_T64(8, 4, 176)
 #undef RF_T64
+            // radius 53..68: row-band passes of the grey loop (the most rows per pass first, then the
+            // most LUT replicas: half the rows is half the lanes, fewer replicas a few bank conflicts)
+            if (!done && t.r4 > 52) {
+                int best_rows = 0, best_rep = 0;
+                for (int rep : {16, 8, 4}) {
+                    const int rows = wide_fits(t, nz, rep);
+                    if (rows > best_rows)
+                        best_rows = rows, best_rep = rep;
+                }
+                if (best_rows > 0) {
+                    rc = best_rep == 16 ? launch_wide<16>(t, nz, best_rows, joint, src, dst, n, h, w,
+                                                          jcn_kernel, src_cn, border, flags, stream)
+                         : best_rep == 8 ? launch_wide<8>(t, nz, best_rows, joint, src, dst, n, h, w,
+                                                          jcn_kernel, src_cn, border, flags, stream)
+                                         : launch_wide<4>(t, nz, best_rows, joint, src, dst, n, h, w,
+                                                          jcn_kernel, src_cn, border, flags, stream);
+                    if (rc != RF_OK)
+                        return rc;
+                    done = true;
+                }
+            }
         }
     }
     int cfg = -1;

@@ -100,18 +100,34 @@ def test_jbf_border_types_flags_and_generic_kernel(env):
     assert np.array_equal(rf.ops.joint_bilateral_u8(j, s, -1, 20, 40)[0].cpu().numpy(), want)
 
 
-@pytest.mark.parametrize("ss,sc", [(28, 15), (34.5, 20), (24.3, 9)])
+@pytest.mark.parametrize("ss,sc", [(28, 15), (34.5, 20), (24.3, 9), (36, 20), (40, 20), (42.9, 12),
+                                   (45.4, 20), (47, 20)])
 def test_jbf_wide_radius_tiles(env, ss, sc):
     """radius 42 / 52 / 36: the 176-texel row pitch (grey and colour tiles) and the pitch
-    boundary; README.md:63 of the reference uses c15 s28."""
+    boundary; README.md:63 of the reference uses c15 s28.  Radius 54 / 60 / 64 / 68 (--sigma_spatial
+    is a free float, /root/reference/filter_reflectance.py:117-119): row-band passes of the grey
+    loop at pitch 208 (32-, 16-, 8-row passes; three passes per band for a colour src); radius 70:
+    beyond the tiles, one thread per pixel.  Grey, colour, 1-channel and mixed grey / colour tiles."""
     from tests import synth
     rf, co, torch = env
     joint = synth.flat_guide_u8(100, 150, seed=int(ss), cells=30)
     grey = synth.reflectance_like_u8(100, 150, seed=3)
     colour = synth.scene_u8(100, 150, seed=4)
-    for src in (grey, colour):
+    mixed = grey.copy()
+    mixed[30:70, 60:110] = colour[30:70, 60:110]           # colour and grey 64x64 tiles in one image
+    for src in (grey, colour, mixed, np.ascontiguousarray(grey[:, :, 0])):
         got = rf.ximgproc.jointBilateralFilter(joint, src, -1, sc, ss)
         assert np.array_equal(got, co.joint_bilateral_filter(joint, src, -1, sc, ss))
+    if ss >= 36:
+        j1 = np.ascontiguousarray(joint[:, :, 1])            # 1-channel joint, REFLECT border, batch of 3
+        import torch as _t
+        jb = _t.from_numpy(np.stack([j1, j1[::-1].copy(), j1])[..., None].copy()).cuda()
+        sb = _t.from_numpy(np.stack([colour, grey, mixed])).cuda()
+        got = rf.ops.joint_bilateral_u8(jb, sb, -1, sc, ss, border=2).cpu().numpy()
+        for i in range(3):
+            want = co.joint_bilateral_filter(jb[i, :, :, 0].cpu().numpy(), sb[i].cpu().numpy(), -1, sc, ss,
+                                             border=2)
+            assert np.array_equal(got[i], want.reshape(got[i].shape)), i
 
 
 def test_jbf_known_answers_on_device(env):

@@ -70,15 +70,25 @@ def main():
     flatj = bench.flat_guide(scene)
     colour_src = scene.roll(shifts=(37, 91), dims=(1, 2)).contiguous()
     dstj = torch.empty_like(scene)
-    for tag, joint, src, sc, ss in (("jbf_c15s28_flat_colour", flatj, colour_src, 15.0, 28.0),
-                                    ("jbf_c15s28_flat_grey", flatj, grey, 15.0, 28.0),
-                                    ("jbf_c20s22_flat_colour", flatj, colour_src, 20.0, 22.0),
-                                    ("jbf_c20s22_flat_grey", flatj, grey, 20.0, 22.0),
-                                    ("jbf_c20s36_generic_colour", flatj[:4], colour_src[:4], 20.0, 36.0)):
+    # (round 5: radius 53..68 run row-band passes of the grey tile loop; the *_generic_* tags keep their
+    #  round-4 names - they now time that form - and "*_untiled_*" is the one-thread-per-pixel kernel
+    #  they fell to before, forced through RF_JBF_FORCE_GENERIC on one image)
+    from reflectance_filtering_amd import _ffi
+    for tag, joint, src, sc, ss, fl in (("jbf_c15s28_flat_colour", flatj, colour_src, 15.0, 28.0, 0),
+                                        ("jbf_c15s28_flat_grey", flatj, grey, 15.0, 28.0, 0),
+                                        ("jbf_c20s22_flat_colour", flatj, colour_src, 20.0, 22.0, 0),
+                                        ("jbf_c20s22_flat_grey", flatj, grey, 20.0, 22.0, 0),
+                                        ("jbf_c20s36_generic_colour", flatj[:8], colour_src[:8], 20.0, 36.0, 0),
+                                        ("jbf_c20s36_generic_grey", flatj[:8], grey[:8], 20.0, 36.0, 0),
+                                        ("jbf_c20s40_bands_colour", flatj[:8], colour_src[:8], 20.0, 40.0, 0),
+                                        ("jbf_c20s40_bands_grey", flatj[:8], grey[:8], 20.0, 40.0, 0),
+                                        ("jbf_c20s36_untiled_colour", flatj[:1], colour_src[:1], 20.0, 36.0,
+                                         _ffi.JBF_FORCE_GENERIC),
+                                        ("jbf_c20s47_untiled_grey", flatj[:1], grey[:1], 20.0, 47.0, 0)):
         radius = int(round(1.5 * ss))
         nb_ = joint.shape[0]
         d_ = dstj[:nb_]
-        ms = timed(torch, lambda: rf.ops.joint_bilateral_u8(joint, src, -1, sc, ss, out=d_), reps=2)
+        ms = timed(torch, lambda: rf.ops.joint_bilateral_u8(joint, src, -1, sc, ss, out=d_, flags=fl), reps=2)
         mp = nb_ * hj * wj / 1e6
         out[tag] = {"ms": ms, "batch": nb_, "radius": radius, "taps_per_px": taps_of(radius),
                     "mp_per_s": mp / (ms * 1e-3),
