@@ -18,8 +18,10 @@
 // Shared pieces: jbf_tap_loop (the software-pipelined tap loop, compiler-scheduled VALU) and
 // jbf_tap_loop_grey4 (its hand-interleaved form for grey tiles; J1 = single-channel joint whose
 // pre-scaled texels make v_sad_u32 produce the gather address).
+#include <atomic>
 #include <cfloat>
 #include <cmath>
+#include <cstring>
 #include <memory>
 #include <mutex>
 #include <type_traits>
@@ -60,21 +62,48 @@ struct JbfTables {
     std::shared_ptr<void> keep;  // JbfTableOwner of the arrays above
 };
 
-// Owns the device arrays of one cache entry.  rf_jbf_u8 keeps a reference for the duration of
-// the call, so an eviction (or rf_shutdown) on another thread cannot free tables that a call has
-// looked up but not launched yet; the last reference frees them on their own device (hipFree
-// waits for the work queued there).  A failed allocation midway frees what was allocated.
+// While alive, this thread may make the "unsafe" runtime calls (allocation, creation of events,
+// synchronisation of OTHER streams) although one of its streams is capturing: the first use of a
+// parameter set inside a graph capture allocates its tables (hipStreamCaptureModeRelaxed for this
+// thread only; the mode is put back on the way out).
+struct CaptureRelax {
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    bool ok;
+    CaptureRelax() { ok = hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess; }
+    ~CaptureRelax()
+    {
+        if (ok)
+            (void)hipThreadExchangeStreamCaptureMode(&mode);
+    }
+};
+
+// Owns the arrays of one cache entry: ONE device arena and its pinned host image (the upload is a
+// single asynchronous copy on the stream of whichever call needs the tables first - stream-ordered,
+// no host synchronisation, capturable: SURVEY.md 8(b) "asynchronous on the passed stream").
+// rf_jbf_u8 keeps a reference for the duration of the call, so an eviction (or rf_shutdown) on
+// another thread cannot free tables that a call has looked up but not launched yet; the last
+// reference frees them on their own device (hipFree waits for the work queued there).  A graph that
+// captured a call keeps using the entry's arrays: it stays valid while the entry is in the cache
+// (64 parameter sets per process, oldest evicted first).
 struct JbfTableOwner {
     int device = 0;
-    void *ptrs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    void *d_arena = nullptr;
+    void *h_arena = nullptr;  // pinned; a captured upload re-reads it on every replay
+    size_t bytes = 0;
+    hipEvent_t uploaded_ev = nullptr;     // recorded behind the first non-captured upload
+    bool ev_recorded = false;             // (under g_mu)
+    std::atomic<bool> resident{false};    // that upload is known to have completed
     ~JbfTableOwner()
     {
         int cur = 0;
         const bool switched = hipGetDevice(&cur) == hipSuccess && cur != device &&
                               hipSetDevice(device) == hipSuccess;
-        for (void *p : ptrs)
-            if (p)
-                (void)hipFree(p);
+        if (d_arena)
+            (void)hipFree(d_arena);
+        if (h_arena)
+            (void)hipHostFree(h_arena);
+        if (uploaded_ev)
+            (void)hipEventDestroy(uploaded_ev);
         if (switched)
             (void)hipSetDevice(cur);
     }
@@ -83,18 +112,56 @@ struct JbfTableOwner {
 std::mutex g_mu;
 std::vector<JbfTables> g_tables;
 
+// Makes the tables of entry t usable by work enqueued on `stream` after this call.  Until an upload
+// is known to have completed, every call enqueues its own copy of the (identical) bytes on its own
+// stream in front of its kernels: calls on different streams need no cross-stream dependency, a
+// capturing stream gets the copy as a node of its graph, and nothing waits on the host.
+int ensure_tables_on(const JbfTables &t, hipStream_t stream)
+{
+    JbfTableOwner *o = static_cast<JbfTableOwner *>(t.keep.get());
+    if (o->resident.load(std::memory_order_acquire))
+        return RF_OK;
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        if (o->ev_recorded && hipEventQuery(o->uploaded_ev) == hipSuccess) {
+            o->resident.store(true, std::memory_order_release);
+            return RF_OK;
+        }
+        (void)hipGetLastError();  // hipErrorNotReady is not an error of this call
+    }
+    RF_HIP_CHECK(hipMemcpyAsync(o->d_arena, o->h_arena, o->bytes, hipMemcpyHostToDevice, stream));
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess) {
+        (void)hipGetLastError();
+        cs = hipStreamCaptureStatusNone;
+    }
+    if (cs == hipStreamCaptureStatusNone) {
+        std::lock_guard<std::mutex> lock(g_mu);
+        if (!o->ev_recorded) {
+            RF_HIP_CHECK(hipEventRecord(o->uploaded_ev, stream));
+            o->ev_recorded = true;
+        }
+    }
+    return RF_OK;
+}
+
 // Host-side parameter tables, computed in double exactly like jointBilateralFilter_8u does.
-int get_tables(int radius, int joint_cn, double sigma_color, double sigma_space, JbfTables *out)
+int get_tables(int radius, int joint_cn, double sigma_color, double sigma_space, hipStream_t stream,
+               JbfTables *out)
 {
     int dev = 0;
     RF_HIP_CHECK(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lock(g_mu);
-    for (const JbfTables &t : g_tables)
-        if (t.device == dev && t.radius == radius && t.joint_cn == joint_cn &&
-            t.sigma_color == sigma_color && t.sigma_space == sigma_space) {
-            *out = t;
-            return RF_OK;
-        }
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        for (const JbfTables &t : g_tables)
+            if (t.device == dev && t.radius == radius && t.joint_cn == joint_cn &&
+                t.sigma_color == sigma_color && t.sigma_space == sigma_space) {
+                *out = t;
+                break;
+            }
+    }
+    if (out->keep)
+        return ensure_tables_on(*out, stream);
     JbfTables t;
     t.device = dev;
     t.radius = radius;
@@ -136,42 +203,65 @@ int get_tables(int radius, int joint_cn, double sigma_color, double sigma_space,
     for (size_t k = 0; k < di.size(); k++)
         if (di[k] >= 0)
             swsym[(size_t)di[k] * t.sw_len + (t.r4 + 8) + dj[k]] = sw[k];
+    // one arena: [swsym][lut][di][dj][sw][hw], every part 256-byte aligned
+    const size_t part[6] = {sizeof(float) * swsym.size(), sizeof(float) * (size_t)nlut,
+                            sizeof(int) * (size_t)t.maxk, sizeof(int) * (size_t)t.maxk,
+                            sizeof(float) * (size_t)t.maxk, sizeof(int) * (size_t)d};
+    const void *from[6] = {swsym.data(), lut.data(), di.data(), dj.data(), sw.data(), hw.data()};
+    size_t off[6], total = 0;
+    for (int k = 0; k < 6; k++) {
+        off[k] = total;
+        total += (part[k] + 255) & ~(size_t)255;
+    }
     auto owner = std::make_shared<JbfTableOwner>();
     owner->device = dev;
+    owner->bytes = total;
     t.keep = owner;
-    RF_HIP_CHECK(hipMalloc(&t.d_swsym, sizeof(float) * swsym.size()));
-    owner->ptrs[0] = t.d_swsym;
-    RF_HIP_CHECK(hipMemcpy(t.d_swsym, swsym.data(), sizeof(float) * swsym.size(),
-                           hipMemcpyHostToDevice));
-    RF_HIP_CHECK(hipMalloc(&t.d_lut, sizeof(float) * nlut));
-    owner->ptrs[1] = t.d_lut;
-    RF_HIP_CHECK(hipMalloc(&t.d_di, sizeof(int) * t.maxk));
-    owner->ptrs[2] = t.d_di;
-    RF_HIP_CHECK(hipMalloc(&t.d_dj, sizeof(int) * t.maxk));
-    owner->ptrs[3] = t.d_dj;
-    RF_HIP_CHECK(hipMalloc(&t.d_sw, sizeof(float) * t.maxk));
-    owner->ptrs[4] = t.d_sw;
-    RF_HIP_CHECK(hipMalloc(&t.d_hw, sizeof(int) * d));
-    owner->ptrs[5] = t.d_hw;
-    RF_HIP_CHECK(hipMemcpy(t.d_lut, lut.data(), sizeof(float) * nlut, hipMemcpyHostToDevice));
-    RF_HIP_CHECK(hipMemcpy(t.d_di, di.data(), sizeof(int) * t.maxk, hipMemcpyHostToDevice));
-    RF_HIP_CHECK(hipMemcpy(t.d_dj, dj.data(), sizeof(int) * t.maxk, hipMemcpyHostToDevice));
-    RF_HIP_CHECK(hipMemcpy(t.d_sw, sw.data(), sizeof(float) * t.maxk, hipMemcpyHostToDevice));
-    RF_HIP_CHECK(hipMemcpy(t.d_hw, hw.data(), sizeof(int) * d, hipMemcpyHostToDevice));
-    // bounded cache (parameter sweeps must not accumulate device memory): drop the oldest entry,
-    // of this device if there is one; its arrays are freed when the last call using them returns
-    if (g_tables.size() >= 64) {
-        size_t victim = 0;
-        for (size_t i = 0; i < g_tables.size(); i++)
-            if (g_tables[i].device == dev) {
-                victim = i;
+    {
+        CaptureRelax relax;  // (the caller's stream may be capturing: see CaptureRelax)
+        RF_HIP_CHECK(hipMalloc(&owner->d_arena, total));
+        RF_HIP_CHECK(hipHostMalloc(&owner->h_arena, total, hipHostMallocDefault));
+        RF_HIP_CHECK(hipEventCreateWithFlags(&owner->uploaded_ev, hipEventDisableTiming));
+    }
+    std::memset(owner->h_arena, 0, total);
+    for (int k = 0; k < 6; k++)
+        std::memcpy(static_cast<char *>(owner->h_arena) + off[k], from[k], part[k]);
+    char *db = static_cast<char *>(owner->d_arena);
+    t.d_swsym = reinterpret_cast<float *>(db + off[0]);
+    t.d_lut = reinterpret_cast<float *>(db + off[1]);
+    t.d_di = reinterpret_cast<int *>(db + off[2]);
+    t.d_dj = reinterpret_cast<int *>(db + off[3]);
+    t.d_sw = reinterpret_cast<float *>(db + off[4]);
+    t.d_hw = reinterpret_cast<int *>(db + off[5]);
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        // (another thread may have built the same entry meanwhile: use that one, ours is freed)
+        bool found = false;
+        for (const JbfTables &e : g_tables)
+            if (e.device == dev && e.radius == radius && e.joint_cn == joint_cn &&
+                e.sigma_color == sigma_color && e.sigma_space == sigma_space) {
+                t = e;
+                found = true;
                 break;
             }
-        g_tables.erase(g_tables.begin() + victim);
+        if (!found) {
+            // bounded cache (parameter sweeps must not accumulate device memory): drop the oldest
+            // entry, of this device if there is one; its arrays are freed when the last call using
+            // them returns
+            if (g_tables.size() >= 64) {
+                size_t victim = 0;
+                for (size_t i = 0; i < g_tables.size(); i++)
+                    if (g_tables[i].device == dev) {
+                        victim = i;
+                        break;
+                    }
+                g_tables.erase(g_tables.begin() + victim);
+            }
+            g_tables.push_back(t);
+        }
     }
-    g_tables.push_back(t);
     *out = t;
-    return RF_OK;
+    return ensure_tables_on(*out, stream);
 }
 
 // Packs up to 3 interleaved bytes into the low bytes of a dword (byte 3 = 0), so that
@@ -1572,14 +1662,25 @@ int lds_oob_reads_zero(int dev, bool *ok)
             return RF_OK;
         }
     }
+    // once per device and process, on a stream of its own, waited for here: the answer selects
+    // kernels.  (The caller's stream may be capturing: CaptureRelax admits the allocation and the
+    // wait on this OTHER stream; nothing of the probe enters the caller's graph.)
+    CaptureRelax relax;
     uint32_t *d_flag = nullptr;
+    hipStream_t ps = nullptr;
+    RF_HIP_CHECK(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
+    struct StreamGuard {
+        hipStream_t s;
+        ~StreamGuard() { (void)hipStreamDestroy(s); }
+    } guard{ps};
     RF_HIP_CHECK(hipMalloc(&d_flag, sizeof(uint32_t)));
-    RF_HIP_CHECK(hipMemset(d_flag, 0, sizeof(uint32_t)));
+    RF_HIP_CHECK(hipMemsetAsync(d_flag, 0, sizeof(uint32_t), ps));
     RF_HIP_CHECK(hipFuncSetAttribute((const void *)lds_oob_probe_kernel,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, kT64Lds));
-    hipLaunchKernelGGL(lds_oob_probe_kernel, dim3(8), dim3(256), kT64Lds, 0, d_flag);
+    hipLaunchKernelGGL(lds_oob_probe_kernel, dim3(8), dim3(256), kT64Lds, ps, d_flag);
     uint32_t flag = 1;
-    RF_HIP_CHECK(hipMemcpy(&flag, d_flag, sizeof(flag), hipMemcpyDeviceToHost));
+    RF_HIP_CHECK(hipMemcpyAsync(&flag, d_flag, sizeof(flag), hipMemcpyDeviceToHost, ps));
+    RF_HIP_CHECK(hipStreamSynchronize(ps));
     (void)hipFree(d_flag);
     std::lock_guard<std::mutex> lock(g_mu);
     g_oob_ok[dev] = flag == 0 ? 1 : 0;
@@ -2040,7 +2141,7 @@ extern "C" int rf_jbf_u8(const uint8_t *joint, const uint8_t *src, uint8_t *dst,
         joint_cn = 3;
     const int jcn_kernel = joint_cn_arg == 1 && joint_cn == 3 ? -1 : joint_cn;
     JbfTables t;
-    int rc = get_tables(radius, joint_cn, sigma_color, sigma_space, &t);
+    int rc = get_tables(radius, joint_cn, sigma_color, sigma_space, stream, &t);
     if (rc != RF_OK)
         return rc;
 
@@ -2206,7 +2307,7 @@ extern "C" int rf_jbf_f32(const float *joint, const float *src, float *dst, int 
         return fail(RF_E_UNSUPPORTED, "rf_jbf_f32: radius %d too large", radius);
     hipStream_t stream = (hipStream_t)stream_;
     JbfTables t;  // tap offsets and spatial weights are those of the 8-bit path
-    int rc = get_tables(radius, joint_cn, sigma_color, sigma_space, &t);
+    int rc = get_tables(radius, joint_cn, sigma_color, sigma_space, stream, &t);
     if (rc != RF_OK)
         return rc;
     // workspace: [n] (min,max) ordered bits | [n] scale_index | [n] tables

@@ -740,6 +740,49 @@ def test_captured_call_with_cnn_and_raw_entry_point_rules(env):
     assert torch.equal(r, want_r)
 
 
+def test_jbf_first_use_of_a_parameter_set_inside_a_capture(env):
+    """asynchronous on the passed stream, no hidden synchronisation.  A (sigma_color,
+    sigma_space) pair the process has never seen is used for the first time INSIDE a graph capture
+    (default, global capture mode): its tables are allocated under a relaxed capture mode and their
+    upload is a node of the graph; the replay gives the oracle's bytes, a second replay after the
+    inputs changed the new bytes, and an eager call on another stream right after the capture (the
+    tables are not resident before the graph first runs) is right as well."""
+    from tests import synth
+    rf, co, torch = env
+    h, w = 90, 140
+    joint = synth.scene_u8(h, w, seed=31)
+    src = synth.reflectance_like_u8(h, w, seed=32)
+    sc, ss = 17.0625, 9.8125              # used nowhere else in the suite: a cache miss
+    j, s = _dev(torch, joint, src)
+    out = torch.zeros_like(s)
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        rf.ops.joint_bilateral_u8(j, s, -1, sc, ss, out=out)
+    other = torch.cuda.Stream()
+    with torch.cuda.stream(other):        # eager, another stream, before the graph ever ran
+        eager = rf.ops.joint_bilateral_u8(j, s, -1, sc, ss)
+    other.synchronize()
+    want = co.joint_bilateral_filter(joint, src, -1, sc, ss)
+    assert np.array_equal(eager[0].cpu().numpy(), want)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(out[0].cpu().numpy(), want)
+    src2 = synth.reflectance_like_u8(h, w, seed=33)
+    s.copy_(torch.from_numpy(src2[None]).cuda())
+    graph.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(out[0].cpu().numpy(), co.joint_bilateral_filter(joint, src2, -1, sc, ss))
+    # a wide radius for the first time, captured too (row-band kernel, LDS probe already done)
+    graph2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph2, stream=side):
+        rf.ops.joint_bilateral_u8(j, s, -1, 11.03125, 36.03125, out=out)
+    graph2.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(out[0].cpu().numpy(),
+                          co.joint_bilateral_filter(joint, src2, -1, 11.03125, 36.03125))
+
+
 def test_gf_capture_on_one_thread_eager_on_another(env):
     """Side streams are per caller stream: while one thread captures a two-image guided-filter
     call into a graph (its side stream joins that capture), another thread calls the filter
