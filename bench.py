@@ -36,6 +36,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_COPY_CEILING_GBS = 6290.0  # MI355X_MICROARCH.md:36: the rate a plain device copy reaches
 JBF_BYTES_PER_PX = 9.0         # 3 B joint + 3 B src read, 3 B dst written
 GF_BYTES_PER_PX_X3 = 21.0      # 3x chain, shared guide, uint8 hand-offs: 9 + 6 + 6
 C3_BYTES_PER_PX = 6.0          # fused chain: 3 B in, 3 B out at the cv2.imread layout
@@ -353,6 +354,35 @@ def valu_roofline(n, h, w, radius, kernel_ms, taps_per_launch, clock_mhz=None):
             "lane_ops_per_tap": VALU_LANE_OPS_PER_S / (taps_per_launch / (kernel_ms * 1e-3))}
 
 
+def lds_cobound(column_steps_per_launch, kernel_ms, clock_mhz=None):
+    """The LDS side of the tap loop, priced like `valu_roofline` prices the VALU side.  Per 4-output
+    column step a wave issues 5 LDS instructions: 4 colour-LUT gathers (ds_read_b32), half a
+    ds_read2_b32 (the texels of two columns per instruction) and half a pair of ds_read_b128 (the
+    weight window of a 4-column group).  A CU's four SIMDs share ONE LDS pipeline; its cost per
+    wave-instruction, from tools/microbench/valu_rates.hip with all four SIMDs issuing
+    (profiles/r01_valu_rates.txt: 8.98 cycles per SIMD = 2.25 per CU for conflict-free b32 / b64 reads,
+    4.2 for fully random gathers): 2.4 cycles for the 32x replicated LUT gather (7 % bank conflicts), 2.25
+    for the ds_read2_b32, 4.5 taken for a ds_read_b128.  `frac` = that floor over the measured launch
+    time; `busy_measured` is SQ_LDS_IDX_ACTIVE over the kernel's CU-cycles from the committed rocprofv3
+    pass (not measured by this run).  With `valu.frac` 0.67 and the LDS pipeline ~0.6 busy in the
+    SAME cycles, the loop sits on two co-saturated floors, not 33 % below one."""
+    per_wave_step = 4 * 2.4 + 0.5 * 2.25 + 0.5 * 2 * 4.5 / 2.0
+    cycles = column_steps_per_launch * per_wave_step / 256.0      # one LDS pipeline per CU
+    mhz = clock_mhz if clock_mhz else 2400.0
+    floor_s = cycles / (mhz * 1e6)
+    busy, src = None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "jbf_pmc_traffic.json")) as fh:
+            rec = json.load(fh)
+        busy, src = rec.get("lds_busy"), rec.get("lds_busy_source")
+    except (OSError, ValueError):
+        pass
+    return {"bound": "lds-issue", "wave_instructions_per_column_step": 5,
+            "lds_cycles_per_wave_step": per_wave_step, "clock_mhz": mhz,
+            "floor_ms": floor_s * 1e3, "frac": floor_s / (kernel_ms * 1e-3),
+            "busy_measured": busy, "busy_source": src}
+
+
 def measured_clock_mhz(torch, rf, step, kernel_ms):
     """Shader clock while `step` runs: launch the step, then the one-wave probe
     (rf_debug_clock_probe) on a second stream for the middle half of the step's duration."""
@@ -488,6 +518,26 @@ def being_profiled():
                                   "ROCPROF_OUTPUT_PATH")) or "rocprofiler" in env.get("LD_PRELOAD", "")
 
 
+# All rocprofv3 child passes of one run share one wall-clock budget (the default run has to stay
+# within a minute or so of driver time whatever the box does): a pass starts only while its
+# predecessor's duration is at most a third of what is left; a skipped pass is said so on stderr
+# and in `traffic_source`, never silently.
+CHILD_BUDGET_S = float(os.environ.get("RF_BENCH_CHILD_BUDGET_S", "70"))
+_child_clock = {"t_end": None, "last": 0.0}
+
+
+def child_pass_allowed():
+    now = time.time()
+    if _child_clock["t_end"] is None:
+        _child_clock["t_end"] = now + CHILD_BUDGET_S
+    left = _child_clock["t_end"] - now
+    return left > 0 and _child_clock["last"] <= left / 3.0, left
+
+
+def child_pass_done(seconds):
+    _child_clock["last"] = seconds
+
+
 def parse_counter_csv(path, counter, match="jbf"):
     """Per-dispatch values of `counter` for the kernels whose name contains `match`, from a
     rocprofv3 *_counter_collection.csv."""
@@ -531,14 +581,18 @@ def live_traffic(args, n, h, w, deadline_s=150.0):
                    "--sigma-color", repr(args.sigma_color), "--sigma-spatial",
                    repr(args.sigma_spatial), "--src", args.src, "--steps", "1", "--warmup", "1",
                    "--cpu-seconds", "0", "--no-extras", "--traffic", "off"]
-            left = t_end - time.time()
-            if left < 20:
-                return None, "no time left for the %s pass" % counter
+            ok, budget_left = child_pass_allowed()
+            left = min(t_end - time.time(), budget_left)
+            if not ok or left < 20:
+                return None, "skipped: no time left in the run's measurement budget for the %s pass" % counter
+            t_pass = time.time()
             try:
                 p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE,
                                    stderr=subprocess.PIPE, timeout=left)
             except subprocess.TimeoutExpired:
+                child_pass_done(time.time() - t_pass)
                 return None, "the %s pass exceeded its time" % counter
+            child_pass_done(time.time() - t_pass)
             files = glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True)
             if p.returncode != 0 or not files:
                 return None, "the %s pass failed (rc %d)" % (counter, p.returncode)
@@ -591,9 +645,11 @@ def live_traffic_config(cfg, batch, deadline_s=90.0):
                    "--", sys.executable, os.path.abspath(__file__), "--config", cfg,
                    "--batch", str(batch), "--steps", "1", "--warmup", "0", "--cpu-seconds", "0",
                    "--no-extras", "--traffic", "off"]
-            left = t_end - time.time()
-            if left < 15:
-                return None, "no time left for the %s pass" % counter
+            ok, budget_left = child_pass_allowed()
+            left = min(t_end - time.time(), budget_left)
+            if not ok or left < 15:
+                return None, "skipped: no time left in the run's measurement budget for the %s pass" % counter
+            t_pass = time.time()
             try:
                 # (run from the repository root.  History: rocprofv3's counter tool crashed - SIGSEGV in
                 #  its own thread - while the C5 guide was generated with ~9,000 tiny torch launches; the
@@ -601,7 +657,9 @@ def live_traffic_config(cfg, batch, deadline_s=90.0):
                 p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE,
                                    stderr=subprocess.PIPE, timeout=left)
             except subprocess.TimeoutExpired:
+                child_pass_done(time.time() - t_pass)
                 return None, "the %s pass exceeded its time" % counter
+            child_pass_done(time.time() - t_pass)
             files = glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True)
             if p.returncode != 0 or not files:
                 return None, "the %s pass failed (rc %d)" % (counter, p.returncode)
@@ -706,6 +764,27 @@ def run_rank(args):
         extras["c2_single_image"] = {"ms": ms, "value": h * w / 1e6 / (ms * 1e-3), "unit": "MP/s",
                                      "note": "one %dx%d image per launch" % (w, h)}
         del j1, s1, d1
+    # HBM-side bytes of the metric launch (the contract's `roofline.traffic`): first in line for the
+    # run's measurement budget, before the other configurations' passes
+    headline_traffic = (None, None)
+    if rank == 0 and not stub:
+        traffic, source = None, None
+        mode = args.traffic
+        if kind == "jbf" and mode != "off":
+            if mode == "live" or (mode == "auto" and world == 1 and not being_profiled()
+                                  and os.environ.get("RF_BENCH_CHILD") != "1"):
+                try:
+                    traffic, source = live_traffic(args, n, h, w)
+                except Exception as exc:              # noqa: BLE001 - a measurement aid, never fatal
+                    traffic, source = None, repr(exc)
+                if traffic is None:
+                    sys.stderr.write("bench.py: live traffic measurement unavailable: %s\n" % source)
+            if traffic is None:
+                traffic, source = committed_traffic(n, h, w)
+                if source:
+                    source += (" (rocprofv3 --pmc passes of this launch shape; not measured by "
+                               "this run)")
+        headline_traffic = (traffic, source)
     image0 = None
     if rank == 0 and not stub and world == 1 and kind == "jbf" and args.cpu_seconds > 0:
         image0 = (wl.joint[0].cpu().numpy(), wl.src[0].cpu().numpy())
@@ -718,6 +797,10 @@ def run_rank(args):
         # 32 GiB) when the device has the room, else at batch 16
         free_b, _ = torch.cuda.mem_get_info()
         c5_batch = CONFIGS["c5"][1] if free_b >= (64 << 30) else 16
+        if c5_batch != CONFIGS["c5"][1]:
+            sys.stderr.write("bench.py: WARNING: only %.1f GiB of device memory free - c5_gf runs at batch "
+                             "%d instead of its %d-image shard (\"batch_reduced\": true in the line)\n"
+                             % (free_b / 2.0 ** 30, c5_batch, CONFIGS["c5"][1]))
         for key, cfg, nb in (("c3_chain", "c3", 256), ("c5_gf", "c5", c5_batch)):
             k2, _, h2, w2 = CONFIGS[cfg]
             w2l = Workload(k2, nb, h2, w2, args, torch, rf, device, seed=1234 + 1000 * int(cfg[1]))
@@ -731,6 +814,21 @@ def run_rank(args):
                                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                         "algorithmic_bytes_per_px": w2l.bytes_per_px}}
             px_step = w2l.pixels
+            if cfg == "c5":
+                extras[key]["batch_reduced"] = nb != CONFIGS["c5"][1]
+                # what the step is made of: its VALU-bound stage 1 alone and its memory-bound row /
+                # column walks alone (timing switches of the library, results discarded): the step is
+                # their SUM minus what the second stream recovers from launch tails - the two classes
+                # cannot share a CU (profiles/r05_c5_overlap.md)
+                alone = {}
+                for part, skip in (("stage1", 6), ("walks", 1)):
+                    with rf._ffi.debug_options(gf_exp_skip=skip):
+                        w2l.step()
+                        _, alone[part] = w2l.timed_steps(2, 1, sharding)
+                w2l.step()                     # leave the buffers as a full step leaves them
+                extras[key]["alone_ms"] = {"stage1_valu_issue_bound": alone["stage1"],
+                                           "row_and_column_walks_memory_bound": alone["walks"],
+                                           "sum": alone["stage1"] + alone["walks"], "step": kms}
             del w2l
             rf.ops.release_workspaces()
             torch.cuda.empty_cache()
@@ -755,6 +853,23 @@ def run_rank(args):
                     if k2 == "gf3":   # a step is three passes over every pixel
                         extras[key]["roofline"]["traffic_bytes_per_px_per_pass"] = (
                             rec["traffic"] / px_step / 3.0)
+                    # the rate the memory side actually runs at (measured bytes over the event-timed
+                    # step), against the rate a plain copy reaches on this chip; for c5 the walks move
+                    # their bytes in `alone_ms.row_and_column_walks_memory_bound`, i.e. faster than
+                    # this step-average says - stage 1's share of the step moves few bytes
+                    ms_side = rec["traffic"] / (kms * 1e-3) / 1e9
+                    extras[key]["roofline"]["memory_side_gbs"] = ms_side
+                    extras[key]["roofline"]["memory_side_frac_of_copy_ceiling"] = (
+                        ms_side / HBM_COPY_CEILING_GBS)
+                    if "alone_ms" in extras[key]:
+                        walks = [v["fetch_bytes"] + v["write_bytes"] for n_, v in rec["kernels"].items()
+                                 if "rowstate" in n_ or "colwalk" in n_]
+                        if walks:
+                            wg = sum(walks) / (extras[key]["alone_ms"]["row_and_column_walks_memory_bound"]
+                                               * 1e-3) / 1e9
+                            extras[key]["roofline"]["walks_alone_gbs"] = wg
+                            extras[key]["roofline"]["walks_alone_frac_of_copy_ceiling"] = (
+                                wg / HBM_COPY_CEILING_GBS)
 
     if world > 1:
         import torch.distributed as dist
@@ -777,22 +892,7 @@ def run_rank(args):
     }
     if not stub:
         achieved = launch_px * wl.bytes_per_px / (kernel_ms * 1e-3) / 1e9
-        traffic, source = None, None
-        mode = args.traffic
-        if kind == "jbf" and mode != "off":
-            if mode == "live" or (mode == "auto" and world == 1 and not being_profiled()
-                                  and os.environ.get("RF_BENCH_CHILD") != "1"):
-                try:
-                    traffic, source = live_traffic(args, n, h, w)
-                except Exception as exc:              # noqa: BLE001 - a measurement aid, never fatal
-                    traffic, source = None, repr(exc)
-                if traffic is None:
-                    sys.stderr.write("bench.py: live traffic measurement unavailable: %s\n" % source)
-            if traffic is None:
-                traffic, source = committed_traffic(n, h, w)
-                if source:
-                    source += (" (rocprofv3 --pmc passes of this launch shape; not measured by "
-                               "this run)")
+        traffic, source = headline_traffic
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                            "traffic_source": source,
@@ -811,6 +911,8 @@ def run_rank(args):
         # tap loop retires 26 VALU wave-instructions per 4-output column step; a gfx950 SIMD
         # issues at most one per 2 cycles (tools/microbench/valu_rates2.hip), 1024 SIMDs, 2.4 GHz.
         out["valu"] = valu_roofline(n, h, w, radius, kernel_ms, launch_px * taps, clock_mhz)
+        # ... and the LDS gather pipeline, co-saturated with it (see lds_cobound)
+        out["lds"] = lds_cobound(out["valu"]["column_steps_per_launch"], kernel_ms, clock_mhz)
         out["config"]["taps_per_px"] = taps
     out.update(extras)
     if image0 is not None:

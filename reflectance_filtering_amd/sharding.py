@@ -3,7 +3,9 @@
 Every image is filtered independently, so multi-GPU operation is pure data
 parallelism: one process per GPU, each takes a contiguous slice of the batch, and there is no
 data-path collective at all (no RCCL traffic over xGMI).  torch.distributed is used only for
-the host-side barrier and for gathering per-rank (pixels, seconds) when measuring.
+the host-side barrier and for gathering per-rank (pixels, seconds) when measuring - two scalars -
+and does that over gloo: no RCCL communicator is brought up unless one is asked for
+(``init_distributed(backend="nccl")`` or ``RF_DIST_BACKEND=nccl``; SURVEY.md 5: "do not add RCCL").
 """
 
 
@@ -37,8 +39,7 @@ def init_distributed(backend=None):
             if backend is None:
                 backend = os.environ.get("RF_DIST_BACKEND")
             if backend is None:
-                import torch
-                backend = "nccl" if torch.cuda.is_available() else "gloo"
+                backend = "gloo"  # host-side barrier + two scalar reductions: nothing for xGMI to carry
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 

@@ -25,6 +25,29 @@ def test_valu_roofline_object():
     assert np.isclose(obj["taps_per_s"], taps / 0.265)
 
 
+def test_lds_cobound_object_and_measurement_budget(monkeypatch):
+    """Round 5: the headline line says what bounds it - `lds` beside `valu` (the tap loop's LDS
+    pipeline priced per column step, plus the committed SQ pass's busy share) - and the rocprofv3
+    child passes of one run share one wall-clock budget."""
+    steps = bench.valu_roofline(256, 1080, 1920, 33, 265.0, 1.0)["column_steps_per_launch"]
+    obj = bench.lds_cobound(steps, 257.0, 2319.0)
+    assert obj["bound"] == "lds-issue" and obj["wave_instructions_per_column_step"] == 5
+    valu = bench.valu_roofline(256, 1080, 1920, 33, 257.0, 1.0, 2319.0)
+    # co-saturated: the LDS floor is within 20 % of the VALU floor for the same launch
+    assert 0.8 < obj["floor_ms"] / valu["floor_ms"] < 1.2 and 0.4 < obj["frac"] < 1.0
+    assert obj["busy_measured"] is None or 0.3 < obj["busy_measured"] < 1.0
+    assert bench.HBM_COPY_CEILING_GBS == 6290.0
+    # budget: a pass may start while the previous one took at most a third of what is left
+    monkeypatch.setattr(bench, "_child_clock", {"t_end": None, "last": 0.0})
+    monkeypatch.setattr(bench, "CHILD_BUDGET_S", 60.0)
+    ok, left = bench.child_pass_allowed()
+    assert ok and 59.0 < left <= 60.0
+    bench.child_pass_done(10.0)
+    assert bench.child_pass_allowed()[0]
+    bench.child_pass_done(25.0)
+    assert not bench.child_pass_allowed()[0]
+
+
 def _run_bench(extra_args, env_extra, timeout=300):
     import json
     import os

@@ -103,6 +103,14 @@ def main():
 
     simds, cus = 1024.0, 256.0
     cols = [("grey src (the metric's launch shape, 32 images)", sq_column("prof_sq", "prof_grbm"))]
+    if cols[0][1]:
+        # bench.py's `lds.busy_measured` reads this (the LDS pipeline's busy share of the metric kernel)
+        c0 = cols[0][1]
+        traffic["lds_busy"] = c0["c"]["SQ_LDS_IDX_ACTIVE"] / cus / c0["gui"]
+        traffic["lds_busy_source"] = ("profiles/%s_jbf_pmc.md: SQ_LDS_IDX_ACTIVE / (256 CUs x GRBM_GUI_ACTIVE / 8), "
+                                      "rocprofv3 --pmc passes of this kernel at batch 32 (tools/prof_bench.sh)" % TAG)
+        with open(os.path.join(OUT, "jbf_pmc_traffic.json"), "w") as fh:
+            json.dump(traffic, fh, indent=1)
     colour = sq_column("prof_sq_colour", "prof_grbm_colour")
     if colour:
         cols.append(("3-channel colour src (32 images)", colour))
