@@ -343,7 +343,18 @@ def valu_roofline(n, h, w, radius, kernel_ms, taps_per_launch, clock_mhz=None):
     floor_peak_s = cycles / 2.4e9
     mhz = clock_mhz if clock_mhz else 2400.0
     floor_s = cycles / (mhz * 1e6)
+    # The same floor priced by instruction class (tools/microbench/valu_rates2.hip, crosslane_rates.hip:
+    # a gfx950 SIMD issues a two-operand fp32 / integer add, subtract, multiply, and, move every 2
+    # cycles and everything else - v_sad_u8, v_lshl_add_u32, v_cvt_f32_ubyte*, v_fma_f32, DPP, fp64 -
+    # every 4): the step's 26 instructions are 17 of the first kind and 9 of the second (4 SADs, 4
+    # gather addresses, 1 conversion) = 70 cycles, not 52.  `frac_of_mix_floor` is the launch against
+    # THAT floor: what is left to win without changing the instruction mix.
+    mix_cycles_per_step = 17 * 2 + 9 * 4
+    mix_floor_s = wave_steps * mix_cycles_per_step / 1024.0 / (mhz * 1e6)
     return {"bound": "valu-issue", "instructions_per_column_step": 26,
+            "issue_cycles_per_column_step_by_class": mix_cycles_per_step,
+            "mix_floor_ms": mix_floor_s * 1e3,
+            "frac_of_mix_floor": mix_floor_s / (kernel_ms * 1e-3),
             "column_steps_per_launch": wave_steps, "clock_mhz": mhz,
             "clock_source": ("s_memtime / s_memrealtime probe beside the launch" if clock_mhz
                              else "2.4 GHz peak (no probe)"),
