@@ -130,6 +130,23 @@ def test_jbf_wide_radius_tiles(env, ss, sc):
             assert np.array_equal(got[i], want.reshape(got[i].shape)), i
 
 
+@pytest.mark.parametrize("d,ss,border", [(109, 3.0, 4), (121, 50.0, 2), (129, 7.5, 0), (137, 22.0, 1),
+                                         (139, 22.0, 3)])
+def test_jbf_wide_diameter_with_any_sigma_and_border(env, d, ss, border):
+    """The radius can also come from `d` (radius = d / 2 whatever sigma_spatial is): 54 / 60 / 64 / 68 on
+    the row-band kernel and 69 on the one-thread-per-pixel kernel, under every border mode, on an
+    image smaller than the radius in one direction (multi-bounce reflection) and a ragged one."""
+    from tests import synth
+    rf, co, torch = env
+    for h, w in ((37, 150), (131, 67)):
+        joint = synth.scene_u8(h, w, seed=d)
+        src = synth.scene_u8(h, w, seed=d + 1)
+        j, s = _dev(torch, joint, src)
+        got = rf.ops.joint_bilateral_u8(j, s, d, 25.0, ss, border=border)[0].cpu().numpy()
+        want = co.joint_bilateral_filter(joint, src, d, 25.0, ss, border=border)
+        assert np.array_equal(got, want), (h, w)
+
+
 def test_jbf_known_answers_on_device(env):
     rf, co, torch = env
     rng = np.random.default_rng(0)
