@@ -1,9 +1,9 @@
 #!/bin/bash
 # Everything behind profiles/<TAG>_* in one go (through gpurun, from the repo root):
-#   gpurun --timeout 3000 -- bash tools/collect_round_profiles.sh r04
+#   gpurun --timeout 3000 -- bash tools/collect_round_profiles.sh r05
 # then copy the summaries from gpurun_out/ into profiles/ (see the last lines).
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 export TMPDIR=/tmp
 O=gpurun_out
 mkdir -p $O
@@ -12,9 +12,9 @@ tools/prof_bench.sh > $O/${TAG}_prof_bench.log 2>&1; python tools/make_profiles.
 tools/prof_c5_traffic.sh $TAG > $O/${TAG}_prof_c5.log 2>&1; python tools/make_profiles_c5.py $TAG > $O/${TAG}_make_c5.log 2>&1
 tools/prof_gf_cnn.sh $TAG 8 > /dev/null 2>&1; python tools/make_profiles_gf.py $TAG 8 > $O/${TAG}_make_gf.log 2>&1
 python tools/bench_other.py > $O/${TAG}_bench_other.json 2> $O/${TAG}_bench_other.err
-python tools/gf_c5_exp.py --rounds 3 --check --out $O/${TAG}_c5_switches.json base gf_no_compact=1 gf_chained=1 gf_one_stream=1 > /dev/null 2>&1
+python tools/gf_c5_exp.py --rounds 3 --check --out $O/${TAG}_c5_switches.json base gf_no_compact=1 gf_chained=1 gf_one_stream=1 gf_stagger=1 gf_s1_cap=3 gf_exp_skip=6 gf_exp_skip=1 > /dev/null 2>&1
 python tools/gf_c5_exp.py --rounds 3 --src colour --batch 64 --out $O/${TAG}_c5_colour.json base gf_one_stream=1 > /dev/null 2>&1
-python tools/fuzz_parity.py --seconds 120 --seed 4 > $O/${TAG}_fuzz_parity.json 2> $O/${TAG}_fuzz.err
+python tools/fuzz_parity.py --seconds 60 --seed 5 > $O/${TAG}_fuzz_parity.json 2> $O/${TAG}_fuzz.err
 python tools/stress_sizes.py > $O/${TAG}_stress_sizes.json 2> $O/${TAG}_stress.err
 # the summaries make_profiles*.py wrote into profiles/ on this box; -n: never over a fresh output above
 cp -n profiles/${TAG}_* profiles/jbf_pmc_traffic.json $O/ 2>/dev/null
