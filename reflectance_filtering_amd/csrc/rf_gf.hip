@@ -1266,24 +1266,67 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
         //  segments of 720 rows per 4K image beat eight of 270 by 2.4 % - 68.8 against 70.5 ms per C5
         //  step, 540 rows 69.1, 405 / 180 / 1080 rows 71.5 / 71.7 / 72.8 - so the segment COUNT is now the
         //  smallest that still gives every place of the chip about one workgroup, not a power of two)
-        auto pick_seg = [&](int strips_k, long long min_wgs, int cap) {
-            if (debug_get(kDbgGfS1MinWgs) > 0)
+        // (round 5: the floor of 3/4 of a window under the segment length was wrong for SMALL work - one
+        //  256x256 image 0.28 ms at 68 rows, 0.10 ms at 1-2; one 1080p image 0.45 / 0.26 ms at 68 / 8 rows;
+        //  16 IIW images 0.42 / 0.25 ms at 68 / 11 - while 4+ images at 4K want 48..68 rows and the shard 720.
+        //  One cost model covers them: a workgroup costs A + seg main-row units (A = its 2r warm-up rows
+        //  at about a fifth of a main row each); k workgroups resident on a CU take crowd[k] times one
+        //  workgroup alone (one wave per SIMD issues every ~6 cycles, four saturate the pipe - stage 1
+        //  alone at 1 / 2 / 3 / 4 workgroups per CU, profiles/r05_c5_overlap.md: k / 1, 1.38, 1.70, 1.87);
+        //  a launch is whole rounds of resident workgroups plus the rest.  The segment count with the
+        //  least modelled time wins.  Against the round-4 rule (debug option "gf_s1_min_wgs" = 960), ms:
+        //  1 x 256x256 0.10 / 0.28, 1 x IIW 0.11 / 0.31, 1 x 1080p 0.26 / 0.44, 1 x 4K 0.48 / 0.58,
+        //  2 x 4K 0.67 / 0.74, 16 x IIW 0.25 / 0.42, 4 x 4K colour 2.12 / 2.24, 32 x 4K x 3 passes 16.6 /
+        //  17.5, 64 x 1080p x 3 8.7 / 9.2; equal at 4 x 4K, 256 x IIW and the C5 shard (65.4 / 65.5).)
+        auto pick_seg = [&](int strips_k, long long min_wgs, int cap, int per_cu) {
+            int seg;
+            if (debug_get(kDbgGfS1MinWgs) > 0) {  // the round-4 rule, kept for A/B runs
                 min_wgs = debug_get(kDbgGfS1MinWgs);
-            const long long per_seg = std::max<long long>(1, (long long)strips_k * m_fill);
-            long long k = (min_wgs + per_seg - 1) / per_seg;          // segments per image
-            k = std::max<long long>(k, ceil_div(h, cap));
-            k = std::min<long long>(std::max<long long>(k, 1), h);
-            int seg = ceil_div(h, (int)k);
-            // (not below 3/4 of a window: 2 / 4 / 8 grey 4K images 0.74 / 0.94 / 1.67 ms at 68 rows, 0.83 /
-            //  1.02 / 1.72 at 108, 1.09 / 1.33 / 2.14 at 180 - small batches want the chip filled)
-            seg = std::max(seg, std::min(h, std::max(3 * (2 * radius + 1) / 4, 32)));
+                const long long per_seg = std::max<long long>(1, (long long)strips_k * m_fill);
+                long long k = (min_wgs + per_seg - 1) / per_seg;          // segments per image
+                k = std::max<long long>(k, ceil_div(h, cap));
+                k = std::min<long long>(std::max<long long>(k, 1), h);
+                seg = ceil_div(h, (int)k);
+                seg = std::max(seg, std::min(h, std::max(3 * (2 * radius + 1) / 4, 32)));
+            } else {
+                const double warm = 0.2 * 2.0 * radius;
+                // time of k resident workgroups on one CU, in units of one workgroup alone
+                static const double crowd[5] = {0.0, 1.0, 2.0 / 1.38, 3.0 / 1.70, 4.0 / 1.87};
+                const long long slots = 256LL * per_cu;
+                double best = 0.0;
+                seg = h;
+                for (int k = std::max(1, ceil_div(h, cap)); k <= h; k++) {
+                    const int sg = ceil_div(h, k);
+                    if (k > 1 && sg == ceil_div(h, k - 1))
+                        continue;  // the same segment length as the previous count
+                    // full rounds of resident workgroups, then the rest on ceil(rest / 256) per CU: a
+                    // launch a little over a whole round pays a whole workgroup's length for the rest
+                    // (4 colour images at 4K: 800 workgroups on 768 places 2.47 ms, 640 on them 2.26)
+                    // (two halves on two streams: the other half's kernels fill the tail of a launch,
+                    //  so beyond one round the workgroups are priced as a fluid - at the C5 shard that
+                    //  keeps round 4's three segments of 720 rows, 63.4 against 64.4 ms with 540)
+                    const long long wgs = (long long)strips_k * m_fill * ceil_div(h, sg);
+                    const long long full = wgs / slots, rest = wgs % slots;
+                    const double t =
+                        (m_fill > P.m && wgs > slots)
+                            ? (warm + sg) * (double)wgs / (double)slots * crowd[per_cu]
+                            : (warm + sg) * ((double)full * crowd[per_cu] +
+                                             (rest ? crowd[(int)((rest + 255) / 256)] : 0.0));
+                    if (best == 0.0 || t < best * 0.999) {
+                        best = t;
+                        seg = sg;
+                    }
+                    if (sg == 1)
+                        break;
+                }
+            }
             seg = ceil_div(h, ceil_div(h, seg));  // equal segments: a launch ends with its longest one
             if (debug_get(kDbgGfSegRows) > 0)
                 seg = std::min(h, debug_get(kDbgGfSegRows));
             return seg;
         };
-        P.seg_rows1 = pick_seg(strips1, 960, h);
-        P.seg_rows3 = pick_seg(strips3, 1024, std::max(6 * (2 * radius + 1), 512));
+        P.seg_rows1 = pick_seg(strips1, 960, h, 4);
+        P.seg_rows3 = pick_seg(strips3, 1024, std::max(6 * (2 * radius + 1), 512), 3);
     };
     // the part's grey probe (flags zeroed by the caller's stream before the fork); with the
     // one-byte hand-off it also leaves every image's channel 0 in cmp for the first pass
