@@ -32,6 +32,19 @@ def jointBilateralFilter(joint, src, d, sigmaColor, sigmaSpace, dst=None,
     """cv2.ximgproc.jointBilateralFilter(joint, src, d, sigmaColor, sigmaSpace[, dst[, borderType]])
     for uint8 or float32 images (both of the same depth) with 1 or 3 channels each."""
     torch = _ffi.require_gpu()
+    # OpenCV's own special case (opencv_contrib joint_bilateral_filter.cpp: `if (joint.empty() ||
+    # src.data == joint.data) { bilateralFilter(src, dst, d, sigmaColor, sigmaSpace, borderType); return; }`):
+    # one buffer passed as both images (or no joint) is filtered by cv::bilateralFilter.  Its 8-bit
+    # path has the same taps, tables and accumulation order; what differs is the last step of a
+    # 1-channel image, `cvRound(sum / wsum)` - a true division - where the joint filter (and its own
+    # 3-channel path) multiply by `1.f / wsum`.  [recalled, unverified like the rest of the OpenCV
+    # arithmetic: DESIGN.md 4.]  The reference never gets here - it reads two files into two buffers
+    # (/root/reference/filter_reflectance.py:84-85) - but a caller passing the same array twice does.
+    same_buffer = joint is None or joint is src or (
+        isinstance(joint, np.ndarray) and isinstance(src, np.ndarray) and joint.shape == src.shape
+        and joint.strides == src.strides and joint.ctypes.data == src.ctypes.data)
+    if joint is None:
+        joint = src
     if np.asarray(joint).shape[:2] != np.asarray(src).shape[:2]:
         raise ValueError("joint and src must have the same size")
     if np.asarray(joint).dtype != np.asarray(src).dtype:
@@ -45,7 +58,8 @@ def jointBilateralFilter(joint, src, d, sigmaColor, sigmaSpace, dst=None,
     if s.dtype == torch.float32:
         out = ops.joint_bilateral_f32(j, s, d, sigmaColor, sigmaSpace, border=borderType)
     else:
-        out = ops.joint_bilateral_u8(j, s, d, sigmaColor, sigmaSpace, border=borderType)
+        flags = _ffi.JBF_TRUE_DIVISION if same_buffer and s.shape[3] == 1 else 0
+        out = ops.joint_bilateral_u8(j, s, d, sigmaColor, sigmaSpace, border=borderType, flags=flags)
     res = _to_host(out, src)
     if dst is not None:
         np.copyto(dst, res)

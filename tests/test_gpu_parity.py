@@ -147,6 +147,27 @@ def test_jbf_wide_diameter_with_any_sigma_and_border(env, d, ss, border):
         assert np.array_equal(got, want), (h, w)
 
 
+def test_jbf_same_buffer_takes_opencvs_bilateral_filter_route(env):
+    """cv2.ximgproc.jointBilateralFilter(a, a, ...) - one buffer as joint and src, or no joint - is
+    routed by OpenCV to cv::bilateralFilter: for a 1-channel image the last step is a true division
+    (the oracle's FLAG_TRUE_DIVISION), for 3 channels the bytes of the joint filter; two equal but
+    separate buffers (the reference's two imreads) stay on the joint filter."""
+    from tests import synth
+    rf, co, torch = env
+    # (the rounding hides the last-ulp difference almost everywhere: this seed has one pixel of 19,200
+    #  where `sum / wsum` and `sum * (1.f / wsum)` round to different bytes)
+    grey = np.ascontiguousarray(synth.scene_u8(120, 160, seed=3)[:, :, 1])
+    colour = synth.scene_u8(61, 83, seed=13)
+    want_div = co.joint_bilateral_filter(grey, grey, -1, 40, 4, flags=co.FLAG_TRUE_DIVISION)
+    want_mul = co.joint_bilateral_filter(grey, grey, -1, 40, 4)
+    assert not np.array_equal(want_div, want_mul)          # the case distinguishes the two routes
+    assert np.array_equal(rf.ximgproc.jointBilateralFilter(grey, grey, -1, 40, 4), want_div)
+    assert np.array_equal(rf.ximgproc.jointBilateralFilter(None, grey, -1, 40, 4), want_div)
+    assert np.array_equal(rf.ximgproc.jointBilateralFilter(grey.copy(), grey, -1, 40, 4), want_mul)
+    want3 = co.joint_bilateral_filter(colour, colour, -1, 30, 5)
+    assert np.array_equal(rf.ximgproc.jointBilateralFilter(colour, colour, -1, 30, 5), want3)
+
+
 def test_jbf_known_answers_on_device(env):
     rf, co, torch = env
     rng = np.random.default_rng(0)
