@@ -188,6 +188,24 @@ def main(argv=None):
                     best["flip_rate"])
             vs["reading"] = msg
             print("%s: %s" % (k, msg))
+        # OpenCV's same-buffer route (jointBilateralFilter(a, a) -> cv::bilateralFilter), which
+        # ximgproc.jointBilateralFilter mirrors for 8-bit images: which last step does a 1-channel
+        # image get there?  (seed 3 has a pixel where `sum / wsum` and `sum * (1.f / wsum)` differ)
+        try:
+            from tests import synth
+            g1 = np.ascontiguousarray(synth.scene_u8(120, 160, seed=3)[:, :, 1])
+            want = cv2.ximgproc.jointBilateralFilter(g1, g1, -1, 40.0, 4.0)
+            div = co.joint_bilateral_filter(g1, g1, -1, 40.0, 4.0, flags=co.FLAG_TRUE_DIVISION)
+            mul = co.joint_bilateral_filter(g1, g1, -1, 40.0, 4.0)
+            report["same_buffer_route"] = {
+                "true_division_vs_opencv": compare(div.reshape(want.shape), want),
+                "reciprocal_multiply_vs_opencv": compare(mul.reshape(want.shape), want),
+                "mirrored_as": "true division for 1-channel images (reflectance_filtering_amd/ximgproc.py)"}
+            if rf is not None:
+                report["same_buffer_route"]["hip_vs_opencv"] = compare(
+                    np.asarray(rf.ximgproc.jointBilateralFilter(g1, g1, -1, 40.0, 4.0)).reshape(want.shape), want)
+        except Exception as exc:                    # noqa: BLE001 - an extra
+            report["same_buffer_route"] = {"error": repr(exc)}
         report["worst_max_abs"] = worst
         report["verdict"] = ("pinned: %d cases byte-identical to OpenCV %s" % (len(compared), cv2.__version__)
                              if compared and worst == 0 else
