@@ -1247,37 +1247,22 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
                           : nullptr;
         P.g0 = guide + (size_t)i0 * npx * 3;
         P.d0 = dst + (size_t)i0 * npx * src_cn;
-        // row segments: enough workgroups to fill 256 CUs, but segments no shorter than 2r+1.
-        // (tools/gf_seg_sweep.py: a pass is flat within 3 % between 34 and 135 rows per segment at
-        // 4K - the 2r warm-up rows of a segment are cheap - and slower above; a model that picks
-        // the segment count by whole rounds of resident workgroups was no better.)
-        // (m_fill: the images whose stage 1 is in flight on the device together - both halves of a
-        // chunk in the aligned schedule, the part alone in the staggered one)
-        // How many workgroups that is depends on the instantiation (each figure measured against
-        // its alternatives in one process).  1-channel kernels: the C5 shard (3 passes; chunks of 37
-        // images, 18 + 19 per half) 14.1 / 14.5 / 14.1-14.3 / 14.0-14.2 GP/s at 135 / 270 / 540 / 1080
-        // rows, i.e. 3,552 / 1,776 / 888 / 444 workgroups in flight; a single pass over 32 images
-        // prefers 135 rows by 4 % (6.20 / 6.45 / 6.56 ms at 135 / 270 / 540) - the chained passes are
-        // what the filter is used for.  The 3-channel kernel (21 running sums: its warm-up rows
-        // cost more) wants fewer and longer segments, but not whole images: 32 images 15.7 / 16.4 /
-        // 17.0 ms at 540 / 270 / 135 rows (1,280 / 2,560 / 5,120 workgroups), 96 images 48.2 / 48.9 /
-        // 50.7 ms at 540 / 270 / 1080 rows.
-        // (round 4, the shard is bound by bytes: every segment reads 2r warm-up rows, and three
-        //  segments of 720 rows per 4K image beat eight of 270 by 2.4 % - 68.8 against 70.5 ms per C5
-        //  step, 540 rows 69.1, 405 / 180 / 1080 rows 71.5 / 71.7 / 72.8 - so the segment COUNT is now the
-        //  smallest that still gives every place of the chip about one workgroup, not a power of two)
-        // (round 5: the floor of 3/4 of a window under the segment length was wrong for SMALL work - one
-        //  256x256 image 0.28 ms at 68 rows, 0.10 ms at 1-2; one 1080p image 0.45 / 0.26 ms at 68 / 8 rows;
-        //  16 IIW images 0.42 / 0.25 ms at 68 / 11 - while 4+ images at 4K want 48..68 rows and the shard 720.
-        //  One cost model covers them: a workgroup costs A + seg main-row units (A = its 2r warm-up rows
-        //  at about a fifth of a main row each); k workgroups resident on a CU take crowd[k] times one
-        //  workgroup alone (one wave per SIMD issues every ~6 cycles, four saturate the pipe - stage 1
-        //  alone at 1 / 2 / 3 / 4 workgroups per CU, profiles/r05_c5_overlap.md: k / 1, 1.38, 1.70, 1.87);
-        //  a launch is whole rounds of resident workgroups plus the rest.  The segment count with the
-        //  least modelled time wins.  Against the round-4 rule (debug option "gf_s1_min_wgs" = 960), ms:
-        //  1 x 256x256 0.10 / 0.28, 1 x IIW 0.11 / 0.31, 1 x 1080p 0.26 / 0.44, 1 x 4K 0.48 / 0.58,
-        //  2 x 4K 0.67 / 0.74, 16 x IIW 0.25 / 0.42, 4 x 4K colour 2.12 / 2.24, 32 x 4K x 3 passes 16.6 /
-        //  17.5, 64 x 1080p x 3 8.7 / 9.2; equal at 4 x 4K, 256 x IIW and the C5 shard (65.4 / 65.5).)
+        // Rows per stage-1 segment (m_fill: the images whose stage 1 is in flight on the device
+        // together - both halves of a chunk in the aligned schedule, the part alone otherwise).  A
+        // workgroup walks its 2r warm-up rows (about a fifth of a main row each: sums only) and then its
+        // segment; more, shorter segments spread small work over the chip, fewer and longer ones waste
+        // less on warm-up rows and re-read fewer bytes.  A small cost model decides: k workgroups
+        // resident on a CU take crowd[k] times one workgroup alone (one wave per SIMD issues every ~6
+        // cycles, four saturate the pipe - stage 1 alone at 1 / 2 / 3 / 4 workgroups per CU,
+        // profiles/r05_c5_overlap.md: k / 1, 1.38, 1.70, 1.87); a launch is whole rounds of resident
+        // workgroups plus the rest; the segment count with the least modelled time wins.  Against the
+        // round-4 rule (>= 960 workgroups, never below 3/4 of a window: debug option "gf_s1_min_wgs" =
+        // 960), ms per call: 1 x 256x256 0.10 / 0.28, 1 x IIW 0.11 / 0.31, 1 x 1080p 0.26 / 0.44,
+        // 1 x 4K 0.48 / 0.58, 2 x 4K 0.67 / 0.74, 16 x IIW 0.25 / 0.42, 4 x 4K colour 2.12 / 2.24,
+        // 32 x 4K x 3 passes 16.6 / 17.5, 64 x 1080p x 3 8.7 / 9.2; equal at 4 x 4K, 256 x IIW and the
+        // C5 shard, which keeps the three segments of 720 rows measured best in round 4
+        // (profiles/r05_gf_seg_sweep.json; the measurements behind the earlier rules: HISTORY.md).
+        // The 3-channel kernel (21 running sums, 3 workgroups per CU) is capped at 6 windows per segment.
         auto pick_seg = [&](int strips_k, long long min_wgs, int cap, int per_cu) {
             int seg;
             if (debug_get(kDbgGfS1MinWgs) > 0) {  // the round-4 rule, kept for A/B runs
