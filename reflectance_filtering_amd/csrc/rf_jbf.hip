@@ -11,10 +11,14 @@
 //   jbf_tile64_kernel  default for radius <= 52: one workgroup = 64x64 output tile (32x128,
 //                      16x256 or 128x32 for the image's remainder rows / columns), 1024 threads
 //                      (4 waves/SIMD), LDS-staged texel tile, LUT at the end of LDS.
+//   jbf_wide_kernel    radius 53..68: the same 64x64 outputs in row-band passes of 32 / 16 / 8 rows
+//                      at row pitch 208 (the grey loop; a colour src one pass per channel).
 //   jbf_tiled2_kernel  64 x TH tiles with 8-byte texels and a clamped/full LUT: used when the
 //                      LDS out-of-range probe fails, and by the tuning harness.
 //   jbf_generic_kernel untiled, any radius, global-memory gathers (fallback + cross-check).
 //   jbf_f32_kernel     the CV_32F variant (rf_jbf_f32), untiled.
+// Parameter tables (colour LUT, tap tables): one device arena per parameter set, uploaded
+// asynchronously on the caller's stream from a pinned host image (get_tables / ensure_tables_on).
 // Shared pieces: jbf_tap_loop (the software-pipelined tap loop, compiler-scheduled VALU) and
 // jbf_tap_loop_grey4 (its hand-interleaved form for grey tiles; J1 = single-channel joint whose
 // pre-scaled texels make v_sad_u32 produce the gather address).
