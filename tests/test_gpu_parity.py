@@ -821,6 +821,34 @@ def test_jbf_first_use_of_a_parameter_set_inside_a_capture(env):
                           co.joint_bilateral_filter(joint, src2, -1, 11.03125, 36.03125))
 
 
+def test_gf_captured_in_the_default_capture_mode(env):
+    """A guided-filter call that forks its side stream (8 images) and runs the staggered schedule's
+    event chain is captured with torch's default (global) capture mode - the call creates events and
+    may create its side stream while the caller's stream is capturing - and replays to the eager
+    bytes, twice."""
+    from tests import synth
+    rf, co, torch = env
+    h, w = 120, 200
+    g = torch.from_numpy(np.stack([synth.flat_guide_u8(h, w, seed=k, cells=10) for k in range(8)])).cuda()
+    s = torch.from_numpy(np.stack([synth.reflectance_like_u8(h, w, seed=20 + k) for k in range(8)])).cuda()
+    want = rf.ops.guided_filter_u8(g, s, 9, 3.0, iterations=2)
+    assert np.array_equal(want[3].cpu().numpy(), co.guided_filter(
+        g[3].cpu().numpy(), co.guided_filter(g[3].cpu().numpy(), s[3].cpu().numpy(), 9, 3.0), 9, 3.0))
+    out = torch.zeros_like(s)
+    ws = rf.ops.gf_workspace(8, h, w, 3, 9, s.device, torch)
+    for opts in ({}, {"gf_stagger": 1, "gf_parts": 4}):
+        side = torch.cuda.Stream()      # a fresh caller stream: its side stream is made inside the capture
+        graph = torch.cuda.CUDAGraph()
+        with rf._ffi.debug_options(**opts):
+            with torch.cuda.graph(graph, stream=side):
+                rf.ops.guided_filter_u8(g, s, 9, 3.0, iterations=2, out=out, workspace=ws)
+        for _ in range(2):
+            out.zero_()
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, want), opts
+
+
 def test_gf_capture_on_one_thread_eager_on_another(env):
     """Side streams are per caller stream: while one thread captures a two-image guided-filter
     call into a graph (its side stream joins that capture), another thread calls the filter
