@@ -343,18 +343,13 @@ def valu_roofline(n, h, w, radius, kernel_ms, taps_per_launch, clock_mhz=None):
     floor_peak_s = cycles / 2.4e9
     mhz = clock_mhz if clock_mhz else 2400.0
     floor_s = cycles / (mhz * 1e6)
-    # The same floor priced by instruction class (tools/microbench/valu_rates2.hip, crosslane_rates.hip:
-    # a gfx950 SIMD issues a two-operand fp32 / integer add, subtract, multiply, and, move every 2
-    # cycles and everything else - v_sad_u8, v_lshl_add_u32, v_cvt_f32_ubyte*, v_fma_f32, DPP, fp64 -
-    # every 4): the step's 26 instructions are 17 of the first kind and 9 of the second (4 SADs, 4
-    # gather addresses, 1 conversion) = 70 cycles, not 52.  `frac_of_mix_floor` is the launch against
-    # THAT floor: what is left to win without changing the instruction mix.
-    mix_cycles_per_step = 17 * 2 + 9 * 4
-    mix_floor_s = wave_steps * mix_cycles_per_step / 1024.0 / (mhz * 1e6)
+    # (The step's 9 four-cycle instructions - 4 v_sad_u8, 4 v_lshl_add_u32, 1 v_cvt_f32_ubyte - are of the
+    # kind that overlaps with a two-cycle neighbour when the stream interleaves them, as the asm loop
+    # does: a v_sad_u8 + v_mul_f32 pair issues in 4.1 cycles, likewise v_lshl_add_u32, v_add3_u32 and
+    # v_cvt_f32_ubyte*; tools/microbench/pipe_overlap.hip, profiles/r05_pipe_overlap.txt.  So 2 cycles
+    # per instruction IS this loop's issue floor; what keeps it at ~0.68 of it is the LDS gather
+    # pipeline working beside it - see lds_cobound.)
     return {"bound": "valu-issue", "instructions_per_column_step": 26,
-            "issue_cycles_per_column_step_by_class": mix_cycles_per_step,
-            "mix_floor_ms": mix_floor_s * 1e3,
-            "frac_of_mix_floor": mix_floor_s / (kernel_ms * 1e-3),
             "column_steps_per_launch": wave_steps, "clock_mhz": mhz,
             "clock_source": ("s_memtime / s_memrealtime probe beside the launch" if clock_mhz
                              else "2.4 GHz peak (no probe)"),
@@ -375,8 +370,9 @@ def lds_cobound(column_steps_per_launch, kernel_ms, clock_mhz=None):
     4.2 for fully random gathers): 2.4 cycles for the 32x replicated LUT gather (7 % bank conflicts), 2.25
     for the ds_read2_b32, 4.5 taken for a ds_read_b128.  `frac` = that floor over the measured launch
     time; `busy_measured` is SQ_LDS_IDX_ACTIVE over the kernel's CU-cycles from the committed rocprofv3
-    pass (not measured by this run).  With `valu.frac` 0.67 and the LDS pipeline ~0.6 busy in the
-    SAME cycles, the loop sits on two co-saturated floors, not 33 % below one."""
+    pass (not measured by this run).  With `valu.frac` 0.67-0.69 and the LDS pipeline's own floor at the
+    same ~0.68 of the launch (0.62 busy measured) in the SAME cycles, the loop sits on two co-saturated
+    floors - every gather's result is the operand of the next multiply - not 32 % below one."""
     per_wave_step = 4 * 2.4 + 0.5 * 2.25 + 0.5 * 2 * 4.5 / 2.0
     cycles = column_steps_per_launch * per_wave_step / 256.0      # one LDS pipeline per CU
     mhz = clock_mhz if clock_mhz else 2400.0
