@@ -36,6 +36,9 @@
  *                        (tools/jbf_tune.py --stage-only, timing only)
  *   "gf_exp_skip"        guided filter, TIMING ONLY, WRONG RESULTS: bit 0 no stage 1, bit 1 no row
  *                        walk, bit 2 no column walk (tools/gf_c5_exp.py)
+ *   "jbf_lookahead1"     joint bilateral: the grey asm tap loop with its LUT gathers one column step
+ *                        ahead of their use and a full wait per step (the round-4 form; the default keeps
+ *                        them two steps ahead, four gathers in flight across a step); identical bytes
  *   "gf_stagger"         guided filter: staggered two-stream schedule - the stage-1 launches of the
  *                        parts of a chunk are chained by events in (pass, part) order, parts alternating
  *                        between the caller's stream and the side stream, so that one part's stage 1

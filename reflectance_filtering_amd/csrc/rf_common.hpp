@@ -91,6 +91,7 @@ enum DebugOption {
     kDbgGfParts,           // guided filter, staggered schedule: parts per chunk (even, default 2)
     kDbgGfS1Cap,           // guided filter: stage-1 workgroups per CU (dynamic-LDS pad), 0 = whatever fits
     kDbgGfS1MinWgs,        // guided filter: workgroups a stage-1 launch should at least have (0 = chosen by the library)
+    kDbgJbfLookahead1,     // joint bilateral: grey asm loop with the gathers one column step ahead (round-4 form)
     kDbgCount
 };
 int debug_get(int id);

@@ -43,6 +43,7 @@ constexpr int kTlw2 = 144;     // tile row pitch in texels of jbf_tiled2_kernel 
 // private flag bits above the public RF_JBF_* ones: the test / benchmark switches of
 // rf_debug_option() as the kernels see them
 constexpr int kJbfStageOnly = 0x1000, kJbfCompilerLoop = 0x2000, kJbfTile64Only = 0x4000;
+constexpr int kJbfLookahead1 = 0x8000;  // grey asm loop with its gathers one column step ahead (round-4 form)
 
 typedef uint32_t uint2v __attribute__((ext_vector_type(2)));
 typedef float float4v __attribute__((ext_vector_type(4)));
@@ -115,6 +116,48 @@ struct JbfTableOwner {
 
 std::mutex g_mu;
 std::vector<JbfTables> g_tables;
+// Owners that left the cache (evicted entries, entries a finishing call held the last reference
+// to): their arrays are freed by the next call whose stream is NOT capturing - hipFree inside a
+// capture invalidates it - or by rf_shutdown.
+std::vector<std::shared_ptr<void>> g_retired;
+
+bool stream_is_capturing(hipStream_t stream)
+{
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return cs != hipStreamCaptureStatusNone;
+}
+
+void drain_retired(hipStream_t stream)
+{
+    if (stream_is_capturing(stream))
+        return;
+    std::vector<std::shared_ptr<void>> bin;
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        bin.swap(g_retired);
+    }
+    if (!bin.empty()) {
+        CaptureRelax relax;  // (another thread of the process may be capturing in the global mode)
+        bin.clear();
+    }
+}
+
+// A call's reference to its tables: if it turns out to be the last one (the entry was evicted while
+// the call was being enqueued), the arrays go to g_retired instead of being freed under the call.
+struct TablesHold {
+    JbfTables &t;
+    ~TablesHold()
+    {
+        if (t.keep && t.keep.use_count() == 1) {
+            std::lock_guard<std::mutex> lock(g_mu);
+            g_retired.push_back(std::move(t.keep));
+        }
+    }
+};
 
 // Makes the tables of entry t usable by work enqueued on `stream` after this call.  Until an upload
 // is known to have completed, every call enqueues its own copy of the (identical) bytes on its own
@@ -134,12 +177,7 @@ int ensure_tables_on(const JbfTables &t, hipStream_t stream)
         (void)hipGetLastError();  // hipErrorNotReady is not an error of this call
     }
     RF_HIP_CHECK(hipMemcpyAsync(o->d_arena, o->h_arena, o->bytes, hipMemcpyHostToDevice, stream));
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(stream, &cs) != hipSuccess) {
-        (void)hipGetLastError();
-        cs = hipStreamCaptureStatusNone;
-    }
-    if (cs == hipStreamCaptureStatusNone) {
+    if (!stream_is_capturing(stream)) {
         std::lock_guard<std::mutex> lock(g_mu);
         if (!o->ev_recorded) {
             RF_HIP_CHECK(hipEventRecord(o->uploaded_ev, stream));
@@ -155,6 +193,7 @@ int get_tables(int radius, int joint_cn, double sigma_color, double sigma_space,
 {
     int dev = 0;
     RF_HIP_CHECK(hipGetDevice(&dev));
+    drain_retired(stream);
     {
         std::lock_guard<std::mutex> lock(g_mu);
         for (const JbfTables &t : g_tables)
@@ -244,6 +283,7 @@ int get_tables(int radius, int joint_cn, double sigma_color, double sigma_space,
         for (const JbfTables &e : g_tables)
             if (e.device == dev && e.radius == radius && e.joint_cn == joint_cn &&
                 e.sigma_color == sigma_color && e.sigma_space == sigma_space) {
+                g_retired.push_back(std::move(t.keep));  // ours: freed later, outside any capture
                 t = e;
                 found = true;
                 break;
@@ -259,6 +299,7 @@ int get_tables(int radius, int joint_cn, double sigma_color, double sigma_space,
                         victim = i;
                         break;
                     }
+                g_retired.push_back(std::move(g_tables[victim].keep));
                 g_tables.erase(g_tables.begin() + victim);
             }
             g_tables.push_back(t);
@@ -938,6 +979,271 @@ __device__ __forceinline__ void jbf_tap_loop_grey4(uint32_t lut_lane_addr, uint3
 #undef RF_G4_TNOUT_3
 }
 
+// jbf_tap_loop_grey4 with the gathers TWO column steps ahead of their use (round 5).  In the form above
+// a column's four LUT gathers are issued in the step before the one that multiplies by them, and the
+// step ends in s_waitcnt lgkmcnt(0): a wave has 8 instructions of its own between issue and wait, the
+// rest of the LDS latency has to come from the SIMD's other three waves - with the CU's one LDS pipeline
+// 62 % busy that is not enough, and VALU and LDS each sit at 0.68 of their floors.  Here step c issues
+// the gathers of column c + 2 and waits with lgkmcnt(4): everything but those four gathers - i.e. the
+// gathers of column c + 1, the texel pair and the weight window - has landed (LDS operations of a wave
+// return in order, so the window is issued BEFORE the step's gathers).  Four gather buffers (indexed by
+// the step within the group), the src byte converted when its texel is at hand for the SAD (two steps
+// before use) so that a texel pair is free for re-use after its second SAD: two pairs still suffice.
+// Same instructions per step, same arithmetic and order: identical bytes.
+template <int LUTREP, int TLW, bool J1 = false>
+__device__ __forceinline__ void jbf_tap_loop_grey4_la2(uint32_t lut_lane_addr, uint32_t sw_addr0,
+                                                       uint32_t tile_lane_addr,
+                                                       const uint32_t (&jc)[kPix], int ty, int radius,
+                                                       int r4, int sw_len,
+                                                       const int *__restrict__ hwtab,
+                                                       float (&sum)[kPix][1], float (&wsum)[kPix])
+{
+    constexpr int Q4 = TLW / 4;
+    constexpr int SHIFT = LUTREP == 32 ? 7 : LUTREP == 16 ? 6 : LUTREP == 8 ? 5 : 4;
+    static_assert(LUTREP == 32 || LUTREP == 16 || LUTREP == 8 || LUTREP == 4, "LUT replicas");
+    static_assert(3 * Q4 + 1 <= 255, "ds_read2_b32 offsets are 8 bits");
+    uint32_t mask = 0x00ffffffu;
+    asm volatile("" : "+v"(mask));  // keep the mask in a VGPR (a literal operand is full-pipe)
+
+    auto row_addr = [&](int i, uint32_t &ta_out, uint32_t &wa_out, int &ngroups_out) {
+        const int hw = hwtab[i + radius];
+        const int hw4 = (hw + 3) & ~3;
+        const int ai = i < 0 ? -i : i;
+        ta_out = tile_lane_addr + (uint32_t)(((ty + i + radius) * TLW + ((r4 - hw4) >> 2)) * 4);
+        wa_out = sw_addr0 + (uint32_t)((ai * sw_len + (r4 + 8) + hw4 - 4) * 4);
+        ngroups_out = (hw4 >> 1) + 1;
+    };
+
+    uint2v tp[2];        // texel pairs: tp[0] = columns (0, 1), tp[1] = columns (2, 3) of a group
+    float4v wna, wnb;    // the group's weight window
+    float gg[4][kPix];   // gg[u]: LUT values of the group's column u (in flight, then consumed at step u)
+    float sv[4];         // sv[u]: src value of column u as float
+    uint32_t ta, wa_addr;
+    int ngroups;
+    row_addr(-radius, ta, wa_addr, ngroups);
+    // prologue: both texel pairs and the weight window of the first group, gathers and src values of
+    // its columns 0 and 1
+    asm volatile("ds_read2_b32 %0, %2 offset1:%3\n\t"
+                 "ds_read2_b32 %1, %2 offset0:%4 offset1:%5"
+                 : "=&v"(tp[0]), "=&v"(tp[1])
+                 : "v"(ta), "n"(Q4), "n"(2 * Q4), "n"(3 * Q4));
+    asm volatile("ds_read_b128 %0, %2\n\t"
+                 "ds_read_b128 %1, %2 offset:16"
+                 : "=&v"(wna), "=&v"(wnb)
+                 : "v"(wa_addr));
+    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(tp[0]), "+v"(tp[1]));
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const uint32_t tx = c == 0 ? tp[0].x : tp[0].y;
+        const uint32_t tj = tx & mask;
+#pragma unroll
+        for (int p = 0; p < kPix; p++) {
+            const uint32_t a =
+                J1 ? (tj > jc[p] ? tj - jc[p] : jc[p] - tj) + lut_lane_addr
+                   : __builtin_amdgcn_sad_u8(tj, jc[p], 0u) * (LUTREP * 4u) + lut_lane_addr;
+            asm volatile("ds_read_b32 %0, %1" : "=v"(gg[c][p]) : "v"(a));
+        }
+        sv[c] = (float)(tx >> 24);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(wna), "+v"(wnb), "+v"(gg[0][0]), "+v"(gg[0][1]), "+v"(gg[0][2]),
+                   "+v"(gg[0][3]), "+v"(gg[1][0]), "+v"(gg[1][1]), "+v"(gg[1][2]), "+v"(gg[1][3]));
+
+#define RF_L2_TQ(U) tp[((U) & 3) >> 1][(U) & 1]
+    // even steps read a texel pair of the NEXT group (or of the next row's first group): step 0 its
+    // columns (0, 1) into tp[0], step 2 its columns (2, 3) into tp[1]
+#define RF_L2_TNOUT(U) RF_L2_TNOUT_##U
+#define RF_L2_TNOUT_0 [tn] "=&v"(tp[0]),
+#define RF_L2_TNOUT_2 [tn] "=&v"(tp[1]),
+#define RF_L2_TNOUT_1
+#define RF_L2_TNOUT_3
+#define RF_L2_READ(U) RF_L2_READ_##U
+#define RF_L2_READ_0 "ds_read2_b32 %[tn], %[ta] offset0:%[o0] offset1:%[o1]\n\t"
+#define RF_L2_READ_2 "ds_read2_b32 %[tn], %[ta] offset0:%[o0] offset1:%[o1]\n\t"
+#define RF_L2_READ_1 ""
+#define RF_L2_READ_3 ""
+    // Step U of a group, first half: [texel pair]; SADs of column U + 2 interleaved with the weights
+    // of column U (GA = its gathered LUT values); src value of column U + 2.
+#define RF_L2_PART1A(U, GA, GB, TA, O0, O1)                                                         \
+    float w0_, w1_, w2_, w3_;                                                                    \
+    uint32_t tj_;                                                                                \
+    asm volatile(RF_L2_READ(U)                                                                   \
+                 "v_and_b32 %[tj], %[mask], %[t2]\n\t"                                           \
+                 "v_sad_u8 %[a0], %[tj], %[jc0], 0\n\t"                                          \
+                 "v_mul_f32 %[w0], %[wv0], %[g0]\n\t"                                            \
+                 "v_sad_u8 %[a1], %[tj], %[jc1], 0\n\t"                                          \
+                 "v_mul_f32 %[w1], %[wv1], %[g1]\n\t"                                            \
+                 "v_sad_u8 %[a2], %[tj], %[jc2], 0\n\t"                                          \
+                 "v_mul_f32 %[w2], %[wv2], %[g2]\n\t"                                            \
+                 "v_sad_u8 %[a3], %[tj], %[jc3], 0\n\t"                                          \
+                 "v_mul_f32 %[w3], %[wv3], %[g3]\n\t"                                            \
+                 "v_cvt_f32_ubyte3 %[s2], %[t2]"                                                 \
+                 : RF_L2_TNOUT(U)[tj] "=&v"(tj_), [a0] "=&v"(GB[0]),                             \
+                   [a1] "=&v"(GB[1]), [a2] "=&v"(GB[2]), [a3] "=&v"(GB[3]), [w0] "=&v"(w0_),     \
+                   [w1] "=&v"(w1_), [w2] "=&v"(w2_), [w3] "=&v"(w3_), [s2] "=&v"(sv[((U) + 2) & 3]) \
+                 : [ta] "v"(TA), [o0] "n"(O0), [o1] "n"(O1), [mask] "v"(mask),                   \
+                   [t2] "v"(RF_L2_TQ((U) + 2)), [jc0] "v"(jc[0]),                                \
+                   [jc1] "v"(jc[1]), [jc2] "v"(jc[2]), [jc3] "v"(jc[3]), [wv0] "v"(wv[4 - (U)]), \
+                   [wv1] "v"(wv[5 - (U)]), [wv2] "v"(wv[6 - (U)]), [wv3] "v"(wv[7 - (U)]),       \
+                   [g0] "v"(GA[0]), [g1] "v"(GA[1]), [g2] "v"(GA[2]), [g3] "v"(GA[3]));
+#define RF_L2_PART1A_J1(U, GA, GB, TA, O0, O1)                                                      \
+    float w0_, w1_, w2_, w3_;                                                                    \
+    uint32_t tj_;                                                                                \
+    asm volatile(RF_L2_READ(U)                                                                   \
+                 "v_and_b32 %[tj], %[mask], %[t2]\n\t"                                           \
+                 "v_sad_u32 %[a0], %[tj], %[jc0], %[la]\n\t"                                     \
+                 "v_mul_f32 %[w0], %[wv0], %[g0]\n\t"                                            \
+                 "v_sad_u32 %[a1], %[tj], %[jc1], %[la]\n\t"                                     \
+                 "v_mul_f32 %[w1], %[wv1], %[g1]\n\t"                                            \
+                 "v_sad_u32 %[a2], %[tj], %[jc2], %[la]\n\t"                                     \
+                 "v_mul_f32 %[w2], %[wv2], %[g2]\n\t"                                            \
+                 "v_sad_u32 %[a3], %[tj], %[jc3], %[la]\n\t"                                     \
+                 "v_mul_f32 %[w3], %[wv3], %[g3]\n\t"                                            \
+                 "v_cvt_f32_ubyte3 %[s2], %[t2]"                                                 \
+                 : RF_L2_TNOUT(U)[tj] "=&v"(tj_), [a0] "=&v"(GB[0]),                             \
+                   [a1] "=&v"(GB[1]), [a2] "=&v"(GB[2]), [a3] "=&v"(GB[3]), [w0] "=&v"(w0_),     \
+                   [w1] "=&v"(w1_), [w2] "=&v"(w2_), [w3] "=&v"(w3_), [s2] "=&v"(sv[((U) + 2) & 3]) \
+                 : [ta] "v"(TA), [o0] "n"(O0), [o1] "n"(O1), [mask] "v"(mask),                   \
+                   [la] "v"(lut_lane_addr), [t2] "v"(RF_L2_TQ((U) + 2)), [jc0] "v"(jc[0]),       \
+                   [jc1] "v"(jc[1]), [jc2] "v"(jc[2]), [jc3] "v"(jc[3]), [wv0] "v"(wv[4 - (U)]), \
+                   [wv1] "v"(wv[5 - (U)]), [wv2] "v"(wv[6 - (U)]), [wv3] "v"(wv[7 - (U)]),       \
+                   [g0] "v"(GA[0]), [g1] "v"(GA[1]), [g2] "v"(GA[2]), [g3] "v"(GA[3]));
+    // second half: gather addresses of column U + 2 interleaved with the weight sums of column U, the
+    // four gathers
+#define RF_L2_PART1B(GB)                                                                         \
+    asm volatile("v_lshl_add_u32 %[a0], %[a0], %[sh], %[la]\n\t"                                 \
+                 "v_add_f32 %[ws0], %[ws0], %[w0]\n\t"                                           \
+                 "v_lshl_add_u32 %[a1], %[a1], %[sh], %[la]\n\t"                                 \
+                 "v_add_f32 %[ws1], %[ws1], %[w1]\n\t"                                           \
+                 "v_lshl_add_u32 %[a2], %[a2], %[sh], %[la]\n\t"                                 \
+                 "v_add_f32 %[ws2], %[ws2], %[w2]\n\t"                                           \
+                 "v_lshl_add_u32 %[a3], %[a3], %[sh], %[la]\n\t"                                 \
+                 "v_add_f32 %[ws3], %[ws3], %[w3]\n\t"                                           \
+                 "ds_read_b32 %[a0], %[a0]\n\t"                                                  \
+                 "ds_read_b32 %[a1], %[a1]\n\t"                                                  \
+                 "ds_read_b32 %[a2], %[a2]\n\t"                                                  \
+                 "ds_read_b32 %[a3], %[a3]"                                                      \
+                 : [a0] "+v"(GB[0]), [a1] "+v"(GB[1]), [a2] "+v"(GB[2]), [a3] "+v"(GB[3]),       \
+                   [ws0] "+v"(wsum[0]), [ws1] "+v"(wsum[1]), [ws2] "+v"(wsum[2]),                \
+                   [ws3] "+v"(wsum[3])                                                           \
+                 : [sh] "n"(SHIFT), [la] "v"(lut_lane_addr), [w0] "v"(w0_), [w1] "v"(w1_),       \
+                   [w2] "v"(w2_), [w3] "v"(w3_));
+#define RF_L2_PART1B_J1(GB)                                                                      \
+    asm volatile("v_add_f32 %[ws0], %[ws0], %[w0]\n\t"                                           \
+                 "v_add_f32 %[ws1], %[ws1], %[w1]\n\t"                                           \
+                 "v_add_f32 %[ws2], %[ws2], %[w2]\n\t"                                           \
+                 "v_add_f32 %[ws3], %[ws3], %[w3]\n\t"                                           \
+                 "ds_read_b32 %[a0], %[a0]\n\t"                                                  \
+                 "ds_read_b32 %[a1], %[a1]\n\t"                                                  \
+                 "ds_read_b32 %[a2], %[a2]\n\t"                                                  \
+                 "ds_read_b32 %[a3], %[a3]"                                                      \
+                 : [a0] "+v"(GB[0]), [a1] "+v"(GB[1]), [a2] "+v"(GB[2]), [a3] "+v"(GB[3]),       \
+                   [ws0] "+v"(wsum[0]), [ws1] "+v"(wsum[1]), [ws2] "+v"(wsum[2]),                \
+                   [ws3] "+v"(wsum[3])                                                           \
+                 : [w0] "v"(w0_), [w1] "v"(w1_), [w2] "v"(w2_), [w3] "v"(w3_));
+    // accumulation of column U (its src value converted two steps ago); then everything but this
+    // step's four gathers has to be there: GN = the gathers of column U + 1, TN = the texel pair read in
+    // this step (any pair for odd steps)
+#define RF_L2_PART2(U, TN, GN, EXTRA_OPERANDS)                                                   \
+    asm volatile("v_mul_f32 %[w0], %[w0], %[s]\n\t"                                              \
+                 "v_mul_f32 %[w1], %[w1], %[s]\n\t"                                              \
+                 "v_mul_f32 %[w2], %[w2], %[s]\n\t"                                              \
+                 "v_mul_f32 %[w3], %[w3], %[s]\n\t"                                              \
+                 "v_add_f32 %[s0], %[s0], %[w0]\n\t"                                             \
+                 "v_add_f32 %[s1], %[s1], %[w1]\n\t"                                             \
+                 "v_add_f32 %[s2], %[s2], %[w2]\n\t"                                             \
+                 "v_add_f32 %[s3], %[s3], %[w3]\n\t"                                             \
+                 "s_waitcnt lgkmcnt(4)"                                                          \
+                 : [w0] "+v"(w0_), [w1] "+v"(w1_), [w2] "+v"(w2_), [w3] "+v"(w3_),               \
+                   [s0] "+v"(sum[0][0]), [s1] "+v"(sum[1][0]), [s2] "+v"(sum[2][0]),             \
+                   [s3] "+v"(sum[3][0]), "+v"(TN), "+v"(GN[0]), "+v"(GN[1]), "+v"(GN[2]),        \
+                   "+v"(GN[3]) EXTRA_OPERANDS                                                    \
+                 : [s] "v"(sv[(U)]));
+#define RF_L2_COMMA_W , "+v"(wna), "+v"(wnb)
+#define RF_L2_LOAD_WINDOW(ADDR)                                                                  \
+    asm volatile("ds_read_b128 %0, %2\n\t"                                                       \
+                 "ds_read_b128 %1, %2 offset:16"                                                 \
+                 : "=&v"(wna), "=&v"(wnb)                                                        \
+                 : "v"(ADDR));
+    // one group of four steps; NB = base address of the texel pairs read ahead (this row's next group
+    // or the next row's first one), with the pair offsets P0A/P0B (columns 0, 1) and P2A/P2B (2, 3);
+    // WLOAD = the statement that loads the next weight window (after the window's last use in step
+    // 3, before that step's gathers)
+#define RF_L2_GROUP(P1A, P1B, NB, P0A, P0B, P2A, P2B, WLOAD)                                      \
+    {                                                                                            \
+        float wv[8];                                                                             \
+        wv[0] = wna.x; wv[1] = wna.y; wv[2] = wna.z; wv[3] = wna.w;                              \
+        wv[4] = wnb.x; wv[5] = wnb.y; wv[6] = wnb.z; wv[7] = wnb.w;                              \
+        {                                                                                        \
+            P1A(0, gg[0], gg[2], NB, P0A, P0B)                                                   \
+            P1B(gg[2])                                                                           \
+            RF_L2_PART2(0, tp[0], gg[1], )                                                       \
+        }                                                                                        \
+        {                                                                                        \
+            P1A(1, gg[1], gg[3], NB, 0, 0)                                                       \
+            P1B(gg[3])                                                                           \
+            RF_L2_PART2(1, tp[0], gg[2], )                                                       \
+        }                                                                                        \
+        {                                                                                        \
+            P1A(2, gg[2], gg[0], NB, P2A, P2B)                                                   \
+            P1B(gg[0])                                                                           \
+            RF_L2_PART2(2, tp[1], gg[3], )                                                       \
+        }                                                                                        \
+        {                                                                                        \
+            P1A(3, gg[3], gg[1], NB, 0, 0)                                                       \
+            WLOAD                                                                                \
+            P1B(gg[1])                                                                           \
+            RF_L2_PART2(3, tp[1], gg[0], RF_L2_COMMA_W)                                          \
+        }                                                                                        \
+    }
+#define RF_L2_ROW_LOOP(P1A, P1B)                                                                  \
+    for (int i = -radius; i <= radius; i++) {                                                     \
+        uint32_t ta_next, wa_next;                                                                \
+        int ngroups_next;                                                                         \
+        row_addr(i < radius ? i + 1 : i, ta_next, wa_next, ngroups_next);                         \
+        for (int gq = 0; gq < ngroups - 1; gq++) {                                                \
+            RF_L2_GROUP(P1A, P1B, ta, 1, Q4 + 1, 2 * Q4 + 1, 3 * Q4 + 1,                          \
+                        wa_addr -= 16; RF_L2_LOAD_WINDOW(wa_addr))                                \
+            ta += 4;                                                                              \
+        }                                                                                         \
+        RF_L2_GROUP(P1A, P1B, ta_next, 0, Q4, 2 * Q4, 3 * Q4, RF_L2_LOAD_WINDOW(wa_next))         \
+        ta = ta_next;                                                                             \
+        wa_addr = wa_next;                                                                        \
+        ngroups = ngroups_next;                                                                   \
+    }
+    if constexpr (J1) {
+        RF_L2_ROW_LOOP(RF_L2_PART1A_J1, RF_L2_PART1B_J1)
+    } else {
+        RF_L2_ROW_LOOP(RF_L2_PART1A, RF_L2_PART1B)
+    }
+    // the last steps' gathers (of a row that does not exist) are still in flight: nothing may re-use
+    // their registers before they have landed
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(gg[0][0]), "+v"(gg[0][1]), "+v"(gg[0][2]), "+v"(gg[0][3]), "+v"(gg[1][0]),
+                   "+v"(gg[1][1]), "+v"(gg[1][2]), "+v"(gg[1][3]), "+v"(tp[0]), "+v"(tp[1]),
+                   "+v"(wna), "+v"(wnb));
+#undef RF_L2_ROW_LOOP
+#undef RF_L2_GROUP
+#undef RF_L2_LOAD_WINDOW
+#undef RF_L2_COMMA_W
+#undef RF_L2_PART2
+#undef RF_L2_PART1B_J1
+#undef RF_L2_PART1B
+#undef RF_L2_PART1A_J1
+#undef RF_L2_PART1A
+#undef RF_L2_READ
+#undef RF_L2_READ_0
+#undef RF_L2_READ_1
+#undef RF_L2_READ_2
+#undef RF_L2_READ_3
+#undef RF_L2_TNOUT
+#undef RF_L2_TNOUT_0
+#undef RF_L2_TNOUT_1
+#undef RF_L2_TNOUT_2
+#undef RF_L2_TNOUT_3
+#undef RF_L2_TQ
+}
+
 // Hand-scheduled tap loop for colour tiles with 6-byte texels (main plane {B,G,R joint, B src},
 // second plane {G src, R src}): the arithmetic and the pipeline of jbf_tap_loop<3, LUTREP, false,
 // TLW, 6>, the row-carried prologue of jbf_tap_loop_grey4.  Per column step 44 VALU instructions,
@@ -1363,12 +1669,19 @@ __global__ __launch_bounds__(1024) void jbf_tile64_kernel(
         if (flags & kJbfCompilerLoop)  // benchmark aid: compiler-scheduled loop instead of the asm one
             jbf_tap_loop<1, GREP, false, TLW, 4>(lut_lane_addr, sw_addr0, tile_lane_addr, 0u, jc, 0u,
                                                  ty, radius, r4, sw_len, hwtab, sum1, wsum);
-        else if (j1 || j1_late)
-            jbf_tap_loop_grey4<GREP, TLW, true>(lut_lane_addr, sw_addr0, tile_lane_addr, jc, ty,
-                                                radius, r4, sw_len, hwtab, sum1, wsum);
+        else if (flags & kJbfLookahead1) {  // A/B aid: the round-4 pipeline depth
+            if (j1 || j1_late)
+                jbf_tap_loop_grey4<GREP, TLW, true>(lut_lane_addr, sw_addr0, tile_lane_addr, jc, ty,
+                                                    radius, r4, sw_len, hwtab, sum1, wsum);
+            else
+                jbf_tap_loop_grey4<GREP, TLW>(lut_lane_addr, sw_addr0, tile_lane_addr, jc, ty, radius,
+                                              r4, sw_len, hwtab, sum1, wsum);
+        } else if (j1 || j1_late)
+            jbf_tap_loop_grey4_la2<GREP, TLW, true>(lut_lane_addr, sw_addr0, tile_lane_addr, jc, ty,
+                                                    radius, r4, sw_len, hwtab, sum1, wsum);
         else
-            jbf_tap_loop_grey4<GREP, TLW>(lut_lane_addr, sw_addr0, tile_lane_addr, jc, ty, radius,
-                                          r4, sw_len, hwtab, sum1, wsum);
+            jbf_tap_loop_grey4_la2<GREP, TLW>(lut_lane_addr, sw_addr0, tile_lane_addr, jc, ty, radius,
+                                              r4, sw_len, hwtab, sum1, wsum);
         store_quad<1, SCN>(dst, img, tile_y0 + ty, tile_x0 + 4 * tx, h, w, sum1, wsum, flags);
         return;
     }
@@ -1580,8 +1893,8 @@ __global__ __launch_bounds__(1024) void jbf_wide_kernel(
                     sum1[p][0] = 0.f;
                     wsum[p] = 0.f;
                 }
-                jbf_tap_loop_grey4<GREP, TLW>(lut_lane_addr, sw_addr0, tile_lane_addr, jc, ty, radius,
-                                              r4, sw_len, hwtab, sum1, wsum);
+                jbf_tap_loop_grey4_la2<GREP, TLW>(lut_lane_addr, sw_addr0, tile_lane_addr, jc, ty,
+                                                  radius, r4, sw_len, hwtab, sum1, wsum);
                 if (scn == 1)
                     store_quad<1, 1>(dst, img, y0 + ty, tile_x0 + 4 * tx, h, w, sum1, wsum, flags);
                 else if (all_grey)
@@ -2095,6 +2408,7 @@ void jbf_shutdown()
 {
     std::lock_guard<std::mutex> lock(g_mu);
     g_tables.clear();  // arrays are freed by their owners (calls in flight keep theirs alive)
+    g_retired.clear();
 }
 
 }  // namespace rf
@@ -2126,7 +2440,8 @@ extern "C" int rf_jbf_u8(const uint8_t *joint, const uint8_t *src, uint8_t *dst,
     // test / benchmark switches (rf_debug_option) travel to the kernels as private flag bits
     flags |= (debug_get(kDbgJbfStageOnly) ? kJbfStageOnly : 0) |
              (debug_get(kDbgJbfCompilerLoop) ? kJbfCompilerLoop : 0) |
-             (debug_get(kDbgJbfTile64Only) ? kJbfTile64Only : 0);
+             (debug_get(kDbgJbfTile64Only) ? kJbfTile64Only : 0) |
+             (debug_get(kDbgJbfLookahead1) ? kJbfLookahead1 : 0);
     // OpenCV: non-positive sigmas become 1; radius from d or from sigma_space
     if (sigma_color <= 0)
         sigma_color = 1;
@@ -2145,6 +2460,7 @@ extern "C" int rf_jbf_u8(const uint8_t *joint, const uint8_t *src, uint8_t *dst,
         joint_cn = 3;
     const int jcn_kernel = joint_cn_arg == 1 && joint_cn == 3 ? -1 : joint_cn;
     JbfTables t;
+    TablesHold hold{t};
     int rc = get_tables(radius, joint_cn, sigma_color, sigma_space, stream, &t);
     if (rc != RF_OK)
         return rc;
@@ -2311,6 +2627,7 @@ extern "C" int rf_jbf_f32(const float *joint, const float *src, float *dst, int 
         return fail(RF_E_UNSUPPORTED, "rf_jbf_f32: radius %d too large", radius);
     hipStream_t stream = (hipStream_t)stream_;
     JbfTables t;  // tap offsets and spatial weights are those of the 8-bit path
+    TablesHold hold{t};
     int rc = get_tables(radius, joint_cn, sigma_color, sigma_space, stream, &t);
     if (rc != RF_OK)
         return rc;

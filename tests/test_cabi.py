@@ -148,6 +148,57 @@ def test_inline_asm_scalar_loads_are_not_touched_before_their_wait(disassembly):
     assert checked > 20, "expected the weight-streaming scalar loads"
 
 
+def _vgprs(text):
+    regs = set()
+    for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", text):
+        regs.update(range(int(a), int(b) + 1))
+    regs.update(int(a) for a in re.findall(r"\bv(\d+)\b", text))
+    return regs
+
+
+def test_lds_reads_in_flight_are_not_touched_before_their_wait(disassembly):
+    """The joint bilateral's asm tap loops issue LDS reads in one inline-asm statement and wait for
+    them in a later one - the round-5 loop keeps four gathers in flight ACROSS a column step
+    (`s_waitcnt lgkmcnt(4)`) - and the compiler does not know they are in flight: nothing between a
+    `ds_read*` and the wait that covers it may read or write its destination VGPRs (a register move
+    would copy a stale value, a re-use would be overwritten when the data lands).  LDS operations of
+    a wave return in order, so `lgkmcnt(n)` leaves at most the n youngest reads pending (scalar loads
+    share the counter and only make a wait stricter).  Checked on the machine code of every
+    joint-bilateral kernel, function ends included (no read may still be pending at `s_endpgm`)."""
+    checked = kernels = 0
+    for name, insts in disassembly.items():
+        if "jbf_" not in name or "f32" in name:
+            continue
+        kernels += 1
+        pending = []                      # destination register sets, oldest first
+        for op, args in insts:
+            if op.startswith("ds_"):     # every LDS operation takes a place in the in-order queue
+                reads = op.startswith("ds_read") or op.startswith("ds_load") or "_rtn" in op
+                dst = _vgprs(args.split(",")[0]) if reads else set()
+                busy = set().union(*pending) if pending else set()
+                assert not (_vgprs(args) & busy), (name, op, args)
+                pending.append(dst)
+                checked += 1 if reads else 0
+                continue
+            if op == "s_waitcnt":
+                m = re.search(r"lgkmcnt\((\d+)\)", args)
+                if m:
+                    keep = int(m.group(1))
+                    pending = pending[len(pending) - keep:] if keep < len(pending) else pending
+                    if keep == 0:
+                        pending = []
+                continue
+            if op in ("s_endpgm", "s_setpc_b64"):
+                assert not pending, (name, op, "LDS reads still in flight at the end")
+                continue
+            if op.startswith("s_cbranch") or op == "s_branch" or op == "s_barrier":
+                continue                  # (control flow: the loops are checked as straight-line text)
+            if pending:
+                busy = set().union(*pending)
+                assert not (_vgprs(args) & busy), (name, op, args, sorted(busy)[:8])
+    assert kernels >= 8 and checked > 2000, (kernels, checked)
+
+
 def test_dpp_reads_respect_the_valu_write_hazard(disassembly):
     """gfx9 needs two wait states between a VALU write of a VGPR and a DPP read of it; the hazard
     recogniser does not look inside inline asm (the guided filter's last scan step is a hand-placed

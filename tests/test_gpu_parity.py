@@ -793,6 +793,12 @@ def test_jbf_first_use_of_a_parameter_set_inside_a_capture(env):
     sc, ss = 17.0625, 9.8125              # used nowhere else in the suite: a cache miss
     j, s = _dev(torch, joint, src)
     out = torch.zeros_like(s)
+    # fill the library's cache of parameter sets (64 per process) so that the captured first use also
+    # EVICTS one: the evicted arrays must not be freed inside the capture (hipFree invalidates it)
+    tiny = torch.zeros((1, 4, 4, 3), dtype=torch.uint8, device="cuda")
+    for k in range(70):
+        rf.ops.joint_bilateral_u8(tiny, tiny.clone(), -1, 31.0 + k / 64.0, 2.0)
+    torch.cuda.synchronize()
     side = torch.cuda.Stream()
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph, stream=side):
