@@ -1144,7 +1144,7 @@ __device__ __forceinline__ void jbf_tap_loop_grey4_la2(uint32_t lut_lane_addr, u
     // accumulation of column U (its src value converted two steps ago); then everything but this
     // step's four gathers has to be there: GN = the gathers of column U + 1, TN = the texel pair read in
     // this step (any pair for odd steps)
-#define RF_L2_PART2(U, TN, GN, EXTRA_OPERANDS)                                                   \
+#define RF_L2_PART2(U, TN, GN, EXTRA_OPERANDS, WAITN)                                                   \
     asm volatile("v_mul_f32 %[w0], %[w0], %[s]\n\t"                                              \
                  "v_mul_f32 %[w1], %[w1], %[s]\n\t"                                              \
                  "v_mul_f32 %[w2], %[w2], %[s]\n\t"                                              \
@@ -1153,13 +1153,20 @@ __device__ __forceinline__ void jbf_tap_loop_grey4_la2(uint32_t lut_lane_addr, u
                  "v_add_f32 %[s1], %[s1], %[w1]\n\t"                                             \
                  "v_add_f32 %[s2], %[s2], %[w2]\n\t"                                             \
                  "v_add_f32 %[s3], %[s3], %[w3]\n\t"                                             \
-                 "s_waitcnt lgkmcnt(4)"                                                          \
+                 "s_waitcnt lgkmcnt(" WAITN ")"                                                  \
                  : [w0] "+v"(w0_), [w1] "+v"(w1_), [w2] "+v"(w2_), [w3] "+v"(w3_),               \
                    [s0] "+v"(sum[0][0]), [s1] "+v"(sum[1][0]), [s2] "+v"(sum[2][0]),             \
                    [s3] "+v"(sum[3][0]), "+v"(TN), "+v"(GN[0]), "+v"(GN[1]), "+v"(GN[2]),        \
-                   "+v"(GN[3]) EXTRA_OPERANDS                                                    \
+                   "+v"(GN[3]) EXTRA_OPERANDS()                                                  \
                  : [s] "v"(sv[(U)]));
-#define RF_L2_COMMA_W , "+v"(wna), "+v"(wnb)
+    // (function-like so that the names travel through the macro levels unexpanded)
+#define RF_L2_NONE()
+#define RF_L2_COMMA_W() , "+v"(wna), "+v"(wnb)
+    // (the last step of a ROW waits for everything, the gathers of the next row's column 1 included:
+    //  the compiler is free to move registers around at the row loop's back edge - a variant of this
+    //  loop got a v_mov of a gather register whose read was in flight there, found by
+    //  tests/test_cabi.py on the machine code - and a row is long enough not to notice one full wait)
+#define RF_L2_COMMA_ALL() , "+v"(wna), "+v"(wnb), "+v"(gg[1][0]), "+v"(gg[1][1]), "+v"(gg[1][2]), "+v"(gg[1][3])
 #define RF_L2_LOAD_WINDOW(ADDR)                                                                  \
     asm volatile("ds_read_b128 %0, %2\n\t"                                                       \
                  "ds_read_b128 %1, %2 offset:16"                                                 \
@@ -1169,7 +1176,7 @@ __device__ __forceinline__ void jbf_tap_loop_grey4_la2(uint32_t lut_lane_addr, u
     // or the next row's first one), with the pair offsets P0A/P0B (columns 0, 1) and P2A/P2B (2, 3);
     // WLOAD = the statement that loads the next weight window (after the window's last use in step
     // 3, before that step's gathers)
-#define RF_L2_GROUP(P1A, P1B, NB, P0A, P0B, P2A, P2B, WLOAD)                                      \
+#define RF_L2_GROUP(P1A, P1B, NB, P0A, P0B, P2A, P2B, WLOAD, WOPS, WAIT3)                         \
     {                                                                                            \
         float wv[8];                                                                             \
         wv[0] = wna.x; wv[1] = wna.y; wv[2] = wna.z; wv[3] = wna.w;                              \
@@ -1177,23 +1184,23 @@ __device__ __forceinline__ void jbf_tap_loop_grey4_la2(uint32_t lut_lane_addr, u
         {                                                                                        \
             P1A(0, gg[0], gg[2], NB, P0A, P0B)                                                   \
             P1B(gg[2])                                                                           \
-            RF_L2_PART2(0, tp[0], gg[1], )                                                       \
+            RF_L2_PART2(0, tp[0], gg[1], RF_L2_NONE, "4")                                                  \
         }                                                                                        \
         {                                                                                        \
             P1A(1, gg[1], gg[3], NB, 0, 0)                                                       \
             P1B(gg[3])                                                                           \
-            RF_L2_PART2(1, tp[0], gg[2], )                                                       \
+            RF_L2_PART2(1, tp[0], gg[2], RF_L2_NONE, "4")                                                  \
         }                                                                                        \
         {                                                                                        \
             P1A(2, gg[2], gg[0], NB, P2A, P2B)                                                   \
             P1B(gg[0])                                                                           \
-            RF_L2_PART2(2, tp[1], gg[3], )                                                       \
+            RF_L2_PART2(2, tp[1], gg[3], RF_L2_NONE, "4")                                                  \
         }                                                                                        \
         {                                                                                        \
             P1A(3, gg[3], gg[1], NB, 0, 0)                                                       \
             WLOAD                                                                                \
             P1B(gg[1])                                                                           \
-            RF_L2_PART2(3, tp[1], gg[0], RF_L2_COMMA_W)                                          \
+            RF_L2_PART2(3, tp[1], gg[0], WOPS, WAIT3)                                            \
         }                                                                                        \
     }
 #define RF_L2_ROW_LOOP(P1A, P1B)                                                                  \
@@ -1203,10 +1210,11 @@ __device__ __forceinline__ void jbf_tap_loop_grey4_la2(uint32_t lut_lane_addr, u
         row_addr(i < radius ? i + 1 : i, ta_next, wa_next, ngroups_next);                         \
         for (int gq = 0; gq < ngroups - 1; gq++) {                                                \
             RF_L2_GROUP(P1A, P1B, ta, 1, Q4 + 1, 2 * Q4 + 1, 3 * Q4 + 1,                          \
-                        wa_addr -= 16; RF_L2_LOAD_WINDOW(wa_addr))                                \
+                        wa_addr -= 16; RF_L2_LOAD_WINDOW(wa_addr), RF_L2_COMMA_W, "4")            \
             ta += 4;                                                                              \
         }                                                                                         \
-        RF_L2_GROUP(P1A, P1B, ta_next, 0, Q4, 2 * Q4, 3 * Q4, RF_L2_LOAD_WINDOW(wa_next))         \
+        RF_L2_GROUP(P1A, P1B, ta_next, 0, Q4, 2 * Q4, 3 * Q4, RF_L2_LOAD_WINDOW(wa_next),         \
+                    RF_L2_COMMA_ALL, "0")                                                         \
         ta = ta_next;                                                                             \
         wa_addr = wa_next;                                                                        \
         ngroups = ngroups_next;                                                                   \
@@ -1225,7 +1233,9 @@ __device__ __forceinline__ void jbf_tap_loop_grey4_la2(uint32_t lut_lane_addr, u
 #undef RF_L2_ROW_LOOP
 #undef RF_L2_GROUP
 #undef RF_L2_LOAD_WINDOW
+#undef RF_L2_COMMA_ALL
 #undef RF_L2_COMMA_W
+#undef RF_L2_NONE
 #undef RF_L2_PART2
 #undef RF_L2_PART1B_J1
 #undef RF_L2_PART1B
