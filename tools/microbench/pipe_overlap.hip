@@ -89,6 +89,16 @@ constexpr int kIters = 4096 * 32;
 #define A_FMA64MUL_CLUST(unused_) asm volatile(F_FMA64(0) F_FMA64(1) F_FMA64(2) F_FMA64(3) F_FMA64(0) F_FMA64(1) F_FMA64(2) F_FMA64(3) S_MULB(4) S_MULB(5) S_MULB(6) S_MULB(7) S_MULB(4) S_MULB(5) S_MULB(6) S_MULB(7) : DREGS);
 #define F_CVT64(x, y) "v_cvt_f32_f64 %" #y ", %" #x "\n"
 #define A_CVT64MUL_INTER(unused_) asm volatile(F_CVT64(0, 4) S_MULB(5) F_CVT64(1, 6) S_MULB(7) F_CVT64(2, 4) S_MULB(5) F_CVT64(3, 6) S_MULB(7) F_CVT64(0, 4) S_MULB(5) F_CVT64(1, 6) S_MULB(7) F_CVT64(2, 4) S_MULB(5) F_CVT64(3, 6) S_MULB(7) : DREGS);
+
+// a multiply whose weight comes from an SGPR (wave-uniform operand) next to a two-cycle add
+#define SREGS "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "s"(b), "v"(b)
+#define F_MULS(x) "v_mul_f32 %" #x ", %8, %" #x "\n"
+#define S_ADDV(x) "v_add_f32 %" #x ", %9, %" #x "\n"
+#define A_MULSGPR_ADD_INTER(unused_) asm volatile(F_MULS(0) S_ADDV(1) F_MULS(2) S_ADDV(3) F_MULS(4) S_ADDV(5) F_MULS(6) S_ADDV(7) F_MULS(1) S_ADDV(0) F_MULS(3) S_ADDV(2) F_MULS(5) S_ADDV(4) F_MULS(7) S_ADDV(6) : SREGS);
+#define A_MULSGPR_ONLY(unused_) asm volatile(F_MULS(0) F_MULS(1) F_MULS(2) F_MULS(3) F_MULS(4) F_MULS(5) F_MULS(6) F_MULS(7) F_MULS(0) F_MULS(1) F_MULS(2) F_MULS(3) F_MULS(4) F_MULS(5) F_MULS(6) F_MULS(7) : SREGS);
+// ... and next to a v_sad_u8 (two "four-cycle" instructions of the hiding kind side by side)
+#define F_SADV(x) "v_sad_u8 %" #x ", %" #x ", %9, 0\n"
+#define A_MULSGPR_SAD_INTER(unused_) asm volatile(F_MULS(0) F_SADV(1) F_MULS(2) F_SADV(3) F_MULS(4) F_SADV(5) F_MULS(6) F_SADV(7) F_MULS(1) F_SADV(0) F_MULS(3) F_SADV(2) F_MULS(5) F_SADV(4) F_MULS(7) F_SADV(6) : SREGS);
 // 64 + 64: clusters as long as stage 1's (the 78 DPP adds of its scan)
 #define A_SADMUL_CLUST64(unused_) asm volatile(F_SAD(0) F_SAD(1) F_SAD(2) F_SAD(3) F_SAD(4) F_SAD(5) F_SAD(6) F_SAD(7) : REGS);
 // waves of even index run only full-pipe instructions, odd ones only simple ones (16 each per OP)
@@ -110,6 +120,9 @@ KERNEL(k_cvtubyte_mul_interleaved, A_CVTUBMUL_INTER)
 KERNEL(k_fma64_mul_interleaved, A_FMA64MUL_INTER)
 KERNEL(k_fma64_mul_clustered8, A_FMA64MUL_CLUST)
 KERNEL(k_cvt64_mul_interleaved, A_CVT64MUL_INTER)
+KERNEL(k_mulsgpr_add_interleaved, A_MULSGPR_ADD_INTER)
+KERNEL(k_mulsgpr_only, A_MULSGPR_ONLY)
+KERNEL(k_mulsgpr_sad_interleaved, A_MULSGPR_SAD_INTER)
 KERNEL(k_split_waves, A_SPLIT_WAVES)
 KERNEL(k_only_sad, A_ONLY_SAD16)
 KERNEL(k_only_mul, A_ONLY_MUL16)
@@ -174,6 +187,9 @@ int main()
     RUN(k_fma64_mul_interleaved, 4);
     RUN(k_fma64_mul_clustered8, 4);
     RUN(k_cvt64_mul_interleaved, 4);
+    RUN(k_mulsgpr_add_interleaved, 4);
+    RUN(k_mulsgpr_only, 4);
+    RUN(k_mulsgpr_sad_interleaved, 4);
     RUN(k_split_waves, 4);
     RUN(k_only_sad, 4);
     RUN(k_only_mul, 4);
