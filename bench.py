@@ -362,18 +362,18 @@ def valu_roofline(n, h, w, radius, kernel_ms, taps_per_launch, clock_mhz=None):
 
 def lds_cobound(column_steps_per_launch, kernel_ms, clock_mhz=None):
     """The LDS side of the tap loop, priced like `valu_roofline` prices the VALU side.  Per 4-output
-    column step a wave issues 5 LDS instructions: 4 colour-LUT gathers (ds_read_b32), half a
-    ds_read2_b32 (the texels of two columns per instruction) and half a pair of ds_read_b128 (the
-    weight window of a 4-column group).  A CU's four SIMDs share ONE LDS pipeline; its cost per
-    wave-instruction, from tools/microbench/valu_rates.hip with all four SIMDs issuing
-    (profiles/r01_valu_rates.txt: 8.98 cycles per SIMD = 2.25 per CU for conflict-free b32 / b64 reads,
-    4.2 for fully random gathers): 2.4 cycles for the 32x replicated LUT gather (7 % bank conflicts), 2.25
-    for the ds_read2_b32, 4.5 taken for a ds_read_b128.  `frac` = that floor over the measured launch
+    column step a wave issues 4.5 LDS instructions: 4 colour-LUT gathers (ds_read_b32) and half a
+    ds_read2_b32 (the texels of two columns per instruction); the weight window of a 4-column group,
+    two broadcast ds_read_b128 until round 5, now comes through a scalar load.  A CU's four SIMDs
+    share ONE LDS pipeline; its cost per wave-instruction, from tools/microbench/valu_rates.hip with all
+    four SIMDs issuing (profiles/r01_valu_rates.txt: 8.98 cycles per SIMD = 2.25 per CU for
+    conflict-free b32 / b64 reads, 4.2 for fully random gathers): 2.4 cycles for the 32x replicated LUT
+    gather (7 % bank conflicts), 2.25 for the ds_read2_b32.  `frac` = that floor over the measured launch
     time; `busy_measured` is SQ_LDS_IDX_ACTIVE over the kernel's CU-cycles from the committed rocprofv3
-    pass (not measured by this run).  With `valu.frac` 0.67-0.69 and the LDS pipeline's own floor at the
-    same ~0.68 of the launch (0.62 busy measured) in the SAME cycles, the loop sits on two co-saturated
-    floors - every gather's result is the operand of the next multiply - not 32 % below one."""
-    per_wave_step = 4 * 2.4 + 0.5 * 2.25 + 0.5 * 2 * 4.5 / 2.0
+    pass (not measured by this run).  VALU issue and the LDS pipeline work in the SAME cycles and are
+    chained - every gather's result is the operand of the next multiply - so the loop sits between two
+    floors, not 30 % below one."""
+    per_wave_step = 4 * 2.4 + 0.5 * 2.25
     cycles = column_steps_per_launch * per_wave_step / 256.0      # one LDS pipeline per CU
     mhz = clock_mhz if clock_mhz else 2400.0
     floor_s = cycles / (mhz * 1e6)
@@ -384,7 +384,7 @@ def lds_cobound(column_steps_per_launch, kernel_ms, clock_mhz=None):
         busy, src = rec.get("lds_busy"), rec.get("lds_busy_source")
     except (OSError, ValueError):
         pass
-    return {"bound": "lds-issue", "wave_instructions_per_column_step": 5,
+    return {"bound": "lds-issue", "wave_instructions_per_column_step": 4.5,
             "lds_cycles_per_wave_step": per_wave_step, "clock_mhz": mhz,
             "floor_ms": floor_s * 1e3, "frac": floor_s / (kernel_ms * 1e-3),
             "busy_measured": busy, "busy_source": src}

@@ -11,8 +11,8 @@
 //   jbf_tile64_kernel  default for radius <= 52: one workgroup = 64x64 output tile (32x128,
 //                      16x256 or 128x32 for the image's remainder rows / columns), 1024 threads
 //                      (4 waves/SIMD), LDS-staged texel tile, LUT at the end of LDS.
-//   jbf_wide_kernel    radius 53..68: the same 64x64 outputs in row-band passes of 32 / 16 / 8 rows
-//                      at row pitch 208 (the grey loop; a colour src one pass per channel).
+//   jbf_wide_kernel    radius 53..72: the same 64x64 outputs in row-band passes of 32 / 16 rows at
+//                      row pitch 208 / 240 (the grey loop; a colour src one pass per channel).
 //   jbf_tiled2_kernel  64 x TH tiles with 8-byte texels and a clamped/full LUT: used when the
 //                      LDS out-of-range probe fails, and by the tuning harness.
 //   jbf_generic_kernel untiled, any radius, global-memory gathers (fallback + cross-check).
@@ -991,7 +991,8 @@ __device__ __forceinline__ void jbf_tap_loop_grey4(uint32_t lut_lane_addr, uint3
 // before use) so that a texel pair is free for re-use after its second SAD: two pairs still suffice.
 // Same instructions per step, same arithmetic and order: identical bytes.
 template <int LUTREP, int TLW, bool J1 = false>
-__device__ __forceinline__ void jbf_tap_loop_grey4_la2(uint32_t lut_lane_addr, uint32_t sw_addr0,
+__device__ __forceinline__ void jbf_tap_loop_grey4_la2(uint32_t lut_lane_addr,
+                                                       const float *__restrict__ swsym,
                                                        uint32_t tile_lane_addr,
                                                        const uint32_t (&jc)[kPix], int ty, int radius,
                                                        int r4, int sw_len,
@@ -1010,12 +1011,19 @@ __device__ __forceinline__ void jbf_tap_loop_grey4_la2(uint32_t lut_lane_addr, u
         const int hw4 = (hw + 3) & ~3;
         const int ai = i < 0 ? -i : i;
         ta_out = tile_lane_addr + (uint32_t)(((ty + i + radius) * TLW + ((r4 - hw4) >> 2)) * 4);
-        wa_out = sw_addr0 + (uint32_t)((ai * sw_len + (r4 + 8) + hw4 - 4) * 4);
+        wa_out = (uint32_t)(ai * sw_len + (r4 + 8) + hw4 - 4);  // index of the first window's first weight
         ngroups_out = (hw4 >> 1) + 1;
     };
 
     uint2v tp[2];        // texel pairs: tp[0] = columns (0, 1), tp[1] = columns (2, 3) of a group
-    float4v wna, wnb;    // the group's weight window
+    // The weight window of a group (8 wave-uniform floats) lives in SGPRs: a v_mul_f32 with an SGPR
+    // operand hides behind its neighbours like the SADs do (a pair with a v_sad_u8 or a v_add_f32 issues
+    // in 4.2 cycles, tools/microbench/pipe_overlap.hip), and two broadcast ds_read_b128 per group - 2 of
+    // the 7 dwords an LDS return carried per step, 5 % of the launch - are gone.  Scalar loads share
+    // lgkmcnt with the LDS and return out of order, so the window of the NEXT group, requested in step 0,
+    // needs a full wait: RF_L2_WAIT_WINDOW, placed where it is free.
+    typedef float float8v __attribute__((ext_vector_type(8)));
+    float8v ws8, wn8;    // this group's window, the next group's
     float gg[4][kPix];   // gg[u]: LUT values of the group's column u (in flight, then consumed at step u)
     float sv[4];         // sv[u]: src value of column u as float
     uint32_t ta, wa_addr;
@@ -1027,11 +1035,11 @@ __device__ __forceinline__ void jbf_tap_loop_grey4_la2(uint32_t lut_lane_addr, u
                  "ds_read2_b32 %1, %2 offset0:%4 offset1:%5"
                  : "=&v"(tp[0]), "=&v"(tp[1])
                  : "v"(ta), "n"(Q4), "n"(2 * Q4), "n"(3 * Q4));
-    asm volatile("ds_read_b128 %0, %2\n\t"
-                 "ds_read_b128 %1, %2 offset:16"
-                 : "=&v"(wna), "=&v"(wnb)
-                 : "v"(wa_addr));
-    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(tp[0]), "+v"(tp[1]));
+    {
+        const float *wp = swsym + wa_addr;
+        asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=&s"(ws8) : "s"(wp));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tp[0]), "+v"(tp[1]), "+s"(ws8));
 #pragma unroll
     for (int c = 0; c < 2; c++) {
         const uint32_t tx = c == 0 ? tp[0].x : tp[0].y;
@@ -1046,7 +1054,7 @@ __device__ __forceinline__ void jbf_tap_loop_grey4_la2(uint32_t lut_lane_addr, u
         sv[c] = (float)(tx >> 24);
     }
     asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(wna), "+v"(wnb), "+v"(gg[0][0]), "+v"(gg[0][1]), "+v"(gg[0][2]),
+                 : "+v"(gg[0][0]), "+v"(gg[0][1]), "+v"(gg[0][2]),
                    "+v"(gg[0][3]), "+v"(gg[1][0]), "+v"(gg[1][1]), "+v"(gg[1][2]), "+v"(gg[1][3]));
 
 #define RF_L2_TQ(U) tp[((U) & 3) >> 1][(U) & 1]
@@ -1083,8 +1091,8 @@ __device__ __forceinline__ void jbf_tap_loop_grey4_la2(uint32_t lut_lane_addr, u
                    [w1] "=&v"(w1_), [w2] "=&v"(w2_), [w3] "=&v"(w3_), [s2] "=&v"(sv[((U) + 2) & 3]) \
                  : [ta] "v"(TA), [o0] "n"(O0), [o1] "n"(O1), [mask] "v"(mask),                   \
                    [t2] "v"(RF_L2_TQ((U) + 2)), [jc0] "v"(jc[0]),                                \
-                   [jc1] "v"(jc[1]), [jc2] "v"(jc[2]), [jc3] "v"(jc[3]), [wv0] "v"(wv[4 - (U)]), \
-                   [wv1] "v"(wv[5 - (U)]), [wv2] "v"(wv[6 - (U)]), [wv3] "v"(wv[7 - (U)]),       \
+                   [jc1] "v"(jc[1]), [jc2] "v"(jc[2]), [jc3] "v"(jc[3]), [wv0] "s"(wv[4 - (U)]), \
+                   [wv1] "s"(wv[5 - (U)]), [wv2] "s"(wv[6 - (U)]), [wv3] "s"(wv[7 - (U)]),       \
                    [g0] "v"(GA[0]), [g1] "v"(GA[1]), [g2] "v"(GA[2]), [g3] "v"(GA[3]));
 #define RF_L2_PART1A_J1(U, GA, GB, TA, O0, O1)                                                      \
     float w0_, w1_, w2_, w3_;                                                                    \
@@ -1105,8 +1113,8 @@ __device__ __forceinline__ void jbf_tap_loop_grey4_la2(uint32_t lut_lane_addr, u
                    [w1] "=&v"(w1_), [w2] "=&v"(w2_), [w3] "=&v"(w3_), [s2] "=&v"(sv[((U) + 2) & 3]) \
                  : [ta] "v"(TA), [o0] "n"(O0), [o1] "n"(O1), [mask] "v"(mask),                   \
                    [la] "v"(lut_lane_addr), [t2] "v"(RF_L2_TQ((U) + 2)), [jc0] "v"(jc[0]),       \
-                   [jc1] "v"(jc[1]), [jc2] "v"(jc[2]), [jc3] "v"(jc[3]), [wv0] "v"(wv[4 - (U)]), \
-                   [wv1] "v"(wv[5 - (U)]), [wv2] "v"(wv[6 - (U)]), [wv3] "v"(wv[7 - (U)]),       \
+                   [jc1] "v"(jc[1]), [jc2] "v"(jc[2]), [jc3] "v"(jc[3]), [wv0] "s"(wv[4 - (U)]), \
+                   [wv1] "s"(wv[5 - (U)]), [wv2] "s"(wv[6 - (U)]), [wv3] "s"(wv[7 - (U)]),       \
                    [g0] "v"(GA[0]), [g1] "v"(GA[1]), [g2] "v"(GA[2]), [g3] "v"(GA[3]));
     // second half: gather addresses of column U + 2 interleaved with the weight sums of column U, the
     // four gathers
@@ -1161,17 +1169,23 @@ __device__ __forceinline__ void jbf_tap_loop_grey4_la2(uint32_t lut_lane_addr, u
                  : [s] "v"(sv[(U)]));
     // (function-like so that the names travel through the macro levels unexpanded)
 #define RF_L2_NONE()
-#define RF_L2_COMMA_W() , "+v"(wna), "+v"(wnb)
     // (the last step of a ROW waits for everything, the gathers of the next row's column 1 included:
     //  the compiler is free to move registers around at the row loop's back edge - a variant of this
     //  loop got a v_mov of a gather register whose read was in flight there, found by
     //  tests/test_cabi.py on the machine code - and a row is long enough not to notice one full wait)
-#define RF_L2_COMMA_ALL() , "+v"(wna), "+v"(wnb), "+v"(gg[1][0]), "+v"(gg[1][1]), "+v"(gg[1][2]), "+v"(gg[1][3])
-#define RF_L2_LOAD_WINDOW(ADDR)                                                                  \
-    asm volatile("ds_read_b128 %0, %2\n\t"                                                       \
-                 "ds_read_b128 %1, %2 offset:16"                                                 \
-                 : "=&v"(wna), "=&v"(wnb)                                                        \
-                 : "v"(ADDR));
+#define RF_L2_COMMA_ALL() , "+v"(gg[1][0]), "+v"(gg[1][1]), "+v"(gg[1][2]), "+v"(gg[1][3])
+    // ... which is waited for in the middle of step 3, where a full wait costs next to nothing: nothing
+    // is in flight there but the gathers of step 2, issued a whole step ago, and the window itself,
+    // requested three steps ago (step 3 reads no texel pair); step 3's own gathers follow the wait
+#define RF_L2_WAIT_WINDOW                                                                        \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                          \
+                 : "+s"(wn8), "+v"(gg[0][0]), "+v"(gg[0][1]), "+v"(gg[0][2]), "+v"(gg[0][3]));
+    // the next group's window: a scalar load of 8 floats from the table in global memory (scalar cache)
+#define RF_L2_LOAD_WINDOW(IDX)                                                                   \
+    {                                                                                            \
+        const float *wp_ = swsym + (IDX);                                                        \
+        asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=&s"(wn8) : "s"(wp_));                      \
+    }
     // one group of four steps; NB = base address of the texel pairs read ahead (this row's next group
     // or the next row's first one), with the pair offsets P0A/P0B (columns 0, 1) and P2A/P2B (2, 3);
     // WLOAD = the statement that loads the next weight window (after the window's last use in step
@@ -1179,8 +1193,9 @@ __device__ __forceinline__ void jbf_tap_loop_grey4_la2(uint32_t lut_lane_addr, u
 #define RF_L2_GROUP(P1A, P1B, NB, P0A, P0B, P2A, P2B, WLOAD, WOPS, WAIT3)                         \
     {                                                                                            \
         float wv[8];                                                                             \
-        wv[0] = wna.x; wv[1] = wna.y; wv[2] = wna.z; wv[3] = wna.w;                              \
-        wv[4] = wnb.x; wv[5] = wnb.y; wv[6] = wnb.z; wv[7] = wnb.w;                              \
+        wv[0] = ws8[0]; wv[1] = ws8[1]; wv[2] = ws8[2]; wv[3] = ws8[3];                          \
+        wv[4] = ws8[4]; wv[5] = ws8[5]; wv[6] = ws8[6]; wv[7] = ws8[7];                          \
+        WLOAD                                                                                    \
         {                                                                                        \
             P1A(0, gg[0], gg[2], NB, P0A, P0B)                                                   \
             P1B(gg[2])                                                                           \
@@ -1198,10 +1213,11 @@ __device__ __forceinline__ void jbf_tap_loop_grey4_la2(uint32_t lut_lane_addr, u
         }                                                                                        \
         {                                                                                        \
             P1A(3, gg[3], gg[1], NB, 0, 0)                                                       \
-            WLOAD                                                                                \
+            RF_L2_WAIT_WINDOW                                                                    \
             P1B(gg[1])                                                                           \
             RF_L2_PART2(3, tp[1], gg[0], WOPS, WAIT3)                                            \
         }                                                                                        \
+        ws8 = wn8;                                                                               \
     }
 #define RF_L2_ROW_LOOP(P1A, P1B)                                                                  \
     for (int i = -radius; i <= radius; i++) {                                                     \
@@ -1210,7 +1226,7 @@ __device__ __forceinline__ void jbf_tap_loop_grey4_la2(uint32_t lut_lane_addr, u
         row_addr(i < radius ? i + 1 : i, ta_next, wa_next, ngroups_next);                         \
         for (int gq = 0; gq < ngroups - 1; gq++) {                                                \
             RF_L2_GROUP(P1A, P1B, ta, 1, Q4 + 1, 2 * Q4 + 1, 3 * Q4 + 1,                          \
-                        wa_addr -= 16; RF_L2_LOAD_WINDOW(wa_addr), RF_L2_COMMA_W, "4")            \
+                        wa_addr -= 4; RF_L2_LOAD_WINDOW(wa_addr), RF_L2_NONE, "4")                \
             ta += 4;                                                                              \
         }                                                                                         \
         RF_L2_GROUP(P1A, P1B, ta_next, 0, Q4, 2 * Q4, 3 * Q4, RF_L2_LOAD_WINDOW(wa_next),         \
@@ -1229,12 +1245,12 @@ __device__ __forceinline__ void jbf_tap_loop_grey4_la2(uint32_t lut_lane_addr, u
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(gg[0][0]), "+v"(gg[0][1]), "+v"(gg[0][2]), "+v"(gg[0][3]), "+v"(gg[1][0]),
                    "+v"(gg[1][1]), "+v"(gg[1][2]), "+v"(gg[1][3]), "+v"(tp[0]), "+v"(tp[1]),
-                   "+v"(wna), "+v"(wnb));
+                   "+s"(ws8), "+s"(wn8));
 #undef RF_L2_ROW_LOOP
 #undef RF_L2_GROUP
 #undef RF_L2_LOAD_WINDOW
+#undef RF_L2_WAIT_WINDOW
 #undef RF_L2_COMMA_ALL
-#undef RF_L2_COMMA_W
 #undef RF_L2_NONE
 #undef RF_L2_PART2
 #undef RF_L2_PART1B_J1
@@ -1687,10 +1703,10 @@ __global__ __launch_bounds__(1024) void jbf_tile64_kernel(
                 jbf_tap_loop_grey4<GREP, TLW>(lut_lane_addr, sw_addr0, tile_lane_addr, jc, ty, radius,
                                               r4, sw_len, hwtab, sum1, wsum);
         } else if (j1 || j1_late)
-            jbf_tap_loop_grey4_la2<GREP, TLW, true>(lut_lane_addr, sw_addr0, tile_lane_addr, jc, ty,
+            jbf_tap_loop_grey4_la2<GREP, TLW, true>(lut_lane_addr, swsym, tile_lane_addr, jc, ty,
                                                     radius, r4, sw_len, hwtab, sum1, wsum);
         else
-            jbf_tap_loop_grey4_la2<GREP, TLW>(lut_lane_addr, sw_addr0, tile_lane_addr, jc, ty, radius,
+            jbf_tap_loop_grey4_la2<GREP, TLW>(lut_lane_addr, swsym, tile_lane_addr, jc, ty, radius,
                                               r4, sw_len, hwtab, sum1, wsum);
         store_quad<1, SCN>(dst, img, tile_y0 + ty, tile_x0 + 4 * tx, h, w, sum1, wsum, flags);
         return;
@@ -1821,29 +1837,30 @@ __device__ inline void store_quad_channel(uint8_t *dst, size_t img, int oy, int 
     }
 }
 
-// Radius 53..68 (--sigma_spatial is a free float of the reference's tool,
-// /root/reference/filter_reflectance.py:117-119: sigma 36 -> radius 54, 40 -> 60): the 64x64 tile
-// with its halo no longer fits the LDS, so a workgroup covers its 64x64 outputs in 64/crows passes of
-// crows rows (32, 16 or 8: whatever the weight table of (r+1) rows leaves room for), each pass
-// staging (crows + 2r) rows of 4-byte texels {B,G,R joint, ONE src byte} at row pitch 208 and running
-// the grey asm tap loop on its first 16*crows threads.  A 3-channel src whose channels differ takes
+// Radius 53..72 (--sigma_spatial is a free float of the reference's tool,
+// /root/reference/filter_reflectance.py:117-119: sigma 36 -> radius 54, 40 -> 60, 47 -> 70): the 64x64
+// tile with its halo no longer fits the LDS, so a workgroup covers its 64x64 outputs in 64/crows passes
+// of crows rows (32 up to radius 68, 16 beyond), each pass staging (crows + 2r) rows of 4-byte texels
+// {B,G,R joint, ONE src byte} at row pitch 208 (240 for radius 69..72) and running the grey asm tap
+// loop on its first 16*crows threads; the weights come through scalar loads, so the LDS holds only the
+// tile and the LUT.  A 3-channel src whose channels differ takes
 // three such passes per row band, one per channel - the weights are formed three times (78 instead
 // of 44 VALU instructions per column step), which is still an order of magnitude below the
 // one-thread-per-pixel kernel these radii fell to before.  Per-pixel tap order and arithmetic are
 // those of every other form: identical bytes.
-template <int GREP>
+template <int GREP, int TLW>
 __global__ __launch_bounds__(1024) void jbf_wide_kernel(
     const uint8_t *__restrict__ joint, const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
     int h, int w, int jcn, int scn, int radius, int border, const float *__restrict__ lut, int nz,
     const int *__restrict__ hwtab, const float *__restrict__ swsym, int sw_len, int tiles_x,
     int tiles_per_img, int flags, int crows)
 {
-    constexpr int NT = 1024, TLW = 208, Q4 = TLW / 4, QW = 16;
+    constexpr int NT = 1024, Q4 = TLW / 4, QW = 16;
+    static_assert(TLW % 32 == 16, "row pitch keeps the rows of a half-wave on disjoint banks");
     extern __shared__ __align__(16) unsigned char smem[];
     int *flag_word = reinterpret_cast<int *>(smem);
-    float *swl = reinterpret_cast<float *>(smem + 16);
-    const int sw_bytes = ((radius + 1) * sw_len * 4 + 15) & ~15;
-    uint32_t *tile4 = reinterpret_cast<uint32_t *>(smem + 16 + sw_bytes);
+    // (no weight table in LDS: the grey loop takes its weight windows through scalar loads)
+    uint32_t *tile4 = reinterpret_cast<uint32_t *>(smem + 16);
     const int tid = threadIdx.x;
     if (tid == 0)
         *flag_word = 3;
@@ -1855,14 +1872,11 @@ __global__ __launch_bounds__(1024) void jbf_wide_kernel(
     const size_t img = (size_t)img_idx * h * w;
     const int r4 = (radius + 3) & ~3;
     const int tx = tid % QW, ty = tid / QW;
-    for (int i = tid; i < (radius + 1) * sw_len; i += NT)
-        swl[i] = swsym[i];
     // the LUT at the very end of the allocation: gathers past its last entry read 0 (probed)
     float *lut_g = reinterpret_cast<float *>(smem + kT64Lds - nz * GREP * 4);
     for (int i = tid; i < nz * GREP; i += NT)
         lut_g[i] = lut[i / GREP];
     const int tlh = crows + 2 * radius;
-    const uint32_t sw_addr0 = lds_addr(swl);
     const uint32_t lut_lane_addr = lds_addr(lut_g) + (uint32_t)(tid & (GREP - 1)) * 4u;
     const uint32_t tile_lane_addr = lds_addr(tile4) + (uint32_t)tx * 4u;
     for (int y0 = tile_y0; y0 < tile_y0 + 64 && y0 < h; y0 += crows) {
@@ -1903,7 +1917,7 @@ __global__ __launch_bounds__(1024) void jbf_wide_kernel(
                     sum1[p][0] = 0.f;
                     wsum[p] = 0.f;
                 }
-                jbf_tap_loop_grey4_la2<GREP, TLW>(lut_lane_addr, sw_addr0, tile_lane_addr, jc, ty,
+                jbf_tap_loop_grey4_la2<GREP, TLW>(lut_lane_addr, swsym, tile_lane_addr, jc, ty,
                                                   radius, r4, sw_len, hwtab, sum1, wsum);
                 if (scn == 1)
                     store_quad<1, 1>(dst, img, y0 + ty, tile_x0 + 4 * tx, h, w, sum1, wsum, flags);
@@ -2119,19 +2133,19 @@ int launch_tile64_rows(const JbfTables &t, int nz, int crows, const uint8_t *joi
     return rc;
 }
 
-// Radius 53..68: rows per pass of jbf_wide_kernel for a LUT replicated grep times (0: does not fit)
-int wide_fits(const JbfTables &t, int nz, int grep)
+// Radius 53..72: rows per pass of jbf_wide_kernel at row pitch tlw for a LUT replicated grep times
+// (0: does not fit).  The LDS holds the tile and the LUT (the weights travel through SGPRs).
+int wide_fits(const JbfTables &t, int nz, int grep, int tlw)
 {
-    if (2 * t.r4 + 64 + 8 > 208)
+    if (2 * t.r4 + 64 + 8 > tlw)
         return 0;
-    const size_t sw_bytes = 16 + (((size_t)(t.radius + 1) * t.sw_len * 4 + 15) & ~(size_t)15);
     for (int crows = 32; crows >= 8; crows >>= 1)
-        if (sw_bytes + (size_t)208 * (crows + 2 * t.radius) * 4 + (size_t)nz * grep * 4 <= (size_t)kT64Lds)
+        if (16 + (size_t)tlw * (crows + 2 * t.radius) * 4 + (size_t)nz * grep * 4 <= (size_t)kT64Lds)
             return crows;
     return 0;
 }
 
-template <int GREP>
+template <int GREP, int TLW>
 int launch_wide(const JbfTables &t, int nz, int crows, const uint8_t *joint, const uint8_t *src,
                 uint8_t *dst, int n, int h, int w, int jcn, int scn, int border, int flags,
                 hipStream_t stream)
@@ -2140,7 +2154,7 @@ int launch_wide(const JbfTables &t, int nz, int crows, const uint8_t *joint, con
     const long long blocks = (long long)tiles_x * tiles_y * n;
     if (blocks > 0x7fffffffLL)
         return fail(RF_E_UNSUPPORTED, "rf_jbf_u8: batch too large for one launch");
-    auto kern = jbf_wide_kernel<GREP>;
+    auto kern = jbf_wide_kernel<GREP, TLW>;
     RF_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      kT64Lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(1024), kT64Lds, stream, joint, src, dst, h,
@@ -2486,7 +2500,7 @@ extern "C" int rf_jbf_u8(const uint8_t *joint, const uint8_t *src, uint8_t *dst,
     // src; the clamp-free 8x table is next
     // tune 7 forces the 64x64 kernel, tune 1..6 the 64xTH kernel
     bool done = false;
-    if (!(flags & RF_JBF_FORCE_GENERIC) && t.r4 <= 68 && (tune == 0 || tune == 7)) {
+    if (!(flags & RF_JBF_FORCE_GENERIC) && t.r4 <= 72 && (tune == 0 || tune == 7)) {
         bool oob_ok = false;
         rc = lds_oob_reads_zero(t.device, &oob_ok);
         if (rc != RF_OK)
@@ -2524,22 +2538,25 @@ extern "C" int rf_jbf_u8(const uint8_t *joint, const uint8_t *src, uint8_t *dst,
             RF_T64(16, 8, 176)
             RF_T64(8, 4, 176)
 #undef RF_T64
-            // radius 53..68: row-band passes of the grey loop (the most rows per pass first, then the
+            // radius 53..72: row-band passes of the grey loop (the most rows per pass first, then the
             // most LUT replicas: half the rows is half the lanes, fewer replicas a few bank conflicts)
             if (!done && t.r4 > 52) {
+                const int tlw = t.r4 <= 68 ? 208 : 240;
                 int best_rows = 0, best_rep = 0;
                 for (int rep : {16, 8, 4}) {
-                    const int rows = wide_fits(t, nz, rep);
+                    const int rows = wide_fits(t, nz, rep, tlw);
                     if (rows > best_rows)
                         best_rows = rows, best_rep = rep;
                 }
                 if (best_rows > 0) {
-                    rc = best_rep == 16 ? launch_wide<16>(t, nz, best_rows, joint, src, dst, n, h, w,
-                                                          jcn_kernel, src_cn, border, flags, stream)
-                         : best_rep == 8 ? launch_wide<8>(t, nz, best_rows, joint, src, dst, n, h, w,
-                                                          jcn_kernel, src_cn, border, flags, stream)
-                                         : launch_wide<4>(t, nz, best_rows, joint, src, dst, n, h, w,
-                                                          jcn_kernel, src_cn, border, flags, stream);
+#define RF_WIDE(REP_, TLW_)                                                                       \
+    launch_wide<REP_, TLW_>(t, nz, best_rows, joint, src, dst, n, h, w, jcn_kernel, src_cn, border, \
+                            flags, stream)
+                    if (tlw == 208)
+                        rc = best_rep == 16 ? RF_WIDE(16, 208) : best_rep == 8 ? RF_WIDE(8, 208) : RF_WIDE(4, 208);
+                    else
+                        rc = best_rep == 16 ? RF_WIDE(16, 240) : best_rep == 8 ? RF_WIDE(8, 240) : RF_WIDE(4, 240);
+#undef RF_WIDE
                     if (rc != RF_OK)
                         return rc;
                     done = true;

@@ -31,10 +31,10 @@ def test_lds_cobound_object_and_measurement_budget(monkeypatch):
     child passes of one run share one wall-clock budget."""
     steps = bench.valu_roofline(256, 1080, 1920, 33, 265.0, 1.0)["column_steps_per_launch"]
     obj = bench.lds_cobound(steps, 257.0, 2319.0)
-    assert obj["bound"] == "lds-issue" and obj["wave_instructions_per_column_step"] == 5
+    assert obj["bound"] == "lds-issue" and obj["wave_instructions_per_column_step"] == 4.5
     valu = bench.valu_roofline(256, 1080, 1920, 33, 257.0, 1.0, 2319.0)
-    # co-saturated: the LDS floor is within 20 % of the VALU floor for the same launch
-    assert 0.8 < obj["floor_ms"] / valu["floor_ms"] < 1.2 and 0.4 < obj["frac"] < 1.0
+    # the LDS floor (4 gathers + half a texel-pair read per step) is 0.7-1.0 of the VALU floor
+    assert 0.7 < obj["floor_ms"] / valu["floor_ms"] < 1.0 and 0.4 < obj["frac"] < 1.0
     assert obj["busy_measured"] is None or 0.3 < obj["busy_measured"] < 1.0
     assert bench.HBM_COPY_CEILING_GBS == 6290.0
     # budget: a pass may start while the previous one took at most a third of what is left

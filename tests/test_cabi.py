@@ -129,8 +129,8 @@ def test_inline_asm_scalar_loads_are_not_touched_before_their_wait(disassembly):
     the machine code of every kernel that streams weights this way."""
     checked = 0
     for name, insts in disassembly.items():
-        if "cnn_reflectance" not in name:
-            continue
+        if "cnn_reflectance" not in name and "jbf_tile64" not in name and "jbf_wide" not in name:
+            continue  # (round 5: the bilateral's grey tap loop streams its weight windows the same way)
         pending = set()
         for op, args in insts:
             if op.startswith("s_load_dword"):

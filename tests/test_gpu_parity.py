@@ -95,19 +95,22 @@ def test_jbf_border_types_flags_and_generic_kernel(env):
     # very wide colour kernel: the LUT has no zero tail (exercises the untruncated table)
     want = co.joint_bilateral_filter(joint, src, -1, 400, 5)
     assert np.array_equal(rf.ops.joint_bilateral_u8(j, s, -1, 400, 5)[0].cpu().numpy(), want)
-    # radius too large for the LDS tile -> generic kernel is picked automatically
+    # radius 60: row-band kernel; radius 75: too large for any LDS tile -> the untiled kernel is picked
     want = co.joint_bilateral_filter(joint, src, -1, 20, 40)
     assert np.array_equal(rf.ops.joint_bilateral_u8(j, s, -1, 20, 40)[0].cpu().numpy(), want)
+    want = co.joint_bilateral_filter(joint, src, -1, 20, 50)
+    assert np.array_equal(rf.ops.joint_bilateral_u8(j, s, -1, 20, 50)[0].cpu().numpy(), want)
 
 
 @pytest.mark.parametrize("ss,sc", [(28, 15), (34.5, 20), (24.3, 9), (36, 20), (40, 20), (42.9, 12),
-                                   (45.4, 20), (47, 20)])
+                                   (45.4, 20), (47, 20), (48.2, 9), (49, 20)])
 def test_jbf_wide_radius_tiles(env, ss, sc):
     """radius 42 / 52 / 36: the 176-texel row pitch (grey and colour tiles) and the pitch
     boundary; README.md:63 of the reference uses c15 s28.  Radius 54 / 60 / 64 / 68 (--sigma_spatial
     is a free float, /root/reference/filter_reflectance.py:117-119): row-band passes of the grey
-    loop at pitch 208 (32-, 16-, 8-row passes; three passes per band for a colour src); radius 70:
-    beyond the tiles, one thread per pixel.  Grey, colour, 1-channel and mixed grey / colour tiles."""
+    loop at pitch 208 (32-row passes; three passes per band for a colour src); radius 70 / 72: the same
+    at pitch 240 in 16-row passes; radius 74 (sigma 49): beyond the tiles, one thread per pixel.  Grey,
+    colour, 1-channel and mixed grey / colour tiles."""
     from tests import synth
     rf, co, torch = env
     joint = synth.flat_guide_u8(100, 150, seed=int(ss), cells=30)
@@ -131,10 +134,10 @@ def test_jbf_wide_radius_tiles(env, ss, sc):
 
 
 @pytest.mark.parametrize("d,ss,border", [(109, 3.0, 4), (121, 50.0, 2), (129, 7.5, 0), (137, 22.0, 1),
-                                         (139, 22.0, 3)])
+                                         (139, 22.0, 3), (145, 22.0, 4), (147, 9.0, 2)])
 def test_jbf_wide_diameter_with_any_sigma_and_border(env, d, ss, border):
-    """The radius can also come from `d` (radius = d / 2 whatever sigma_spatial is): 54 / 60 / 64 / 68 on
-    the row-band kernel and 69 on the one-thread-per-pixel kernel, under every border mode, on an
+    """The radius can also come from `d` (radius = d / 2 whatever sigma_spatial is): 54 / 60 / 64 / 68 / 69 /
+    72 on the row-band kernel and 73 on the one-thread-per-pixel kernel, under every border mode, on an
     image smaller than the radius in one direction (multi-bounce reflection) and a ragged one."""
     from tests import synth
     rf, co, torch = env

@@ -70,7 +70,7 @@ def main():
     flatj = bench.flat_guide(scene)
     colour_src = scene.roll(shifts=(37, 91), dims=(1, 2)).contiguous()
     dstj = torch.empty_like(scene)
-    # (round 5: radius 53..68 run row-band passes of the grey tile loop; the *_generic_* tags keep their
+    # (round 5: radius 53..72 run row-band passes of the grey tile loop; the *_generic_* tags keep their
     #  round-4 names - they now time that form - and "*_untiled_*" is the one-thread-per-pixel kernel
     #  they fell to before, forced through RF_JBF_FORCE_GENERIC on one image)
     from reflectance_filtering_amd import _ffi
@@ -84,7 +84,8 @@ def main():
                                         ("jbf_c20s40_bands_grey", flatj[:8], grey[:8], 20.0, 40.0, 0),
                                         ("jbf_c20s36_untiled_colour", flatj[:1], colour_src[:1], 20.0, 36.0,
                                          _ffi.JBF_FORCE_GENERIC),
-                                        ("jbf_c20s47_untiled_grey", flatj[:1], grey[:1], 20.0, 47.0, 0)):
+                                        ("jbf_c20s47_bands_grey", flatj[:8], grey[:8], 20.0, 47.0, 0),
+                                        ("jbf_c20s51_untiled_grey", flatj[:1], grey[:1], 20.0, 51.0, 0)):
         radius = int(round(1.5 * ss))
         nb_ = joint.shape[0]
         d_ = dstj[:nb_]
