@@ -1277,7 +1277,8 @@ __device__ __forceinline__ void jbf_tap_loop_grey4_la2(uint32_t lut_lane_addr,
 // 4 v_lshl_add_u32, 3 v_cvt_f32_ubyte*; hipcc emits the SADs and address computations as one
 // burst of nine, here each full-pipe instruction is followed by a simple one (v_mul/v_add).
 template <int LUTREP, int TLW>
-__device__ __forceinline__ void jbf_tap_loop_rgb6(uint32_t lut_lane_addr, uint32_t sw_addr0,
+__device__ __forceinline__ void jbf_tap_loop_rgb6(uint32_t lut_lane_addr,
+                                                  const float *__restrict__ swsym,
                                                   uint32_t tile_lane_addr,
                                                   uint32_t plane_b_lane_addr,
                                                   const uint32_t (&jc)[kPix], int ty, int radius,
@@ -1299,12 +1300,16 @@ __device__ __forceinline__ void jbf_tap_loop_rgb6(uint32_t lut_lane_addr, uint32
         const uint32_t texel0 = (uint32_t)((ty + i + radius) * TLW + ((r4 - hw4) >> 2));
         ta_out = tile_lane_addr + texel0 * 4;
         tb_out = plane_b_lane_addr + texel0 * 2;
-        wa_out = sw_addr0 + (uint32_t)((ai * sw_len + (r4 + 8) + hw4 - 4) * 4);
+        wa_out = (uint32_t)(ai * sw_len + (r4 + 8) + hw4 - 4);  // index of the first window's first weight
         ngroups_out = (hw4 >> 1) + 1;
     };
 
     uint32_t tq[4], tqb[4];
-    float4v wna, wnb;
+    // the weight window of a group in SGPRs, as in jbf_tap_loop_grey4_la2: every step ends with a full
+    // wait here, so the scalar load of the next window (issued in step 3, after that step's gathers)
+    // needs no wait of its own
+    typedef float float8v __attribute__((ext_vector_type(8)));
+    float8v ws8, wn8;
     float gg[2][kPix];
     uint32_t ta, tb, wa_addr;
     int ngroups;
@@ -1316,11 +1321,13 @@ __device__ __forceinline__ void jbf_tap_loop_rgb6(uint32_t lut_lane_addr, uint32
                  "ds_read_u16 %3, %5 offset:%7"
                  : "=&v"(tq[0]), "=&v"(tq[1]), "=&v"(tqb[0]), "=&v"(tqb[1])
                  : "v"(ta), "v"(tb), "n"(Q4 * 4), "n"(Q4 * 2));
-    asm volatile("ds_read_b128 %0, %2\n\t"
-                 "ds_read_b128 %1, %2 offset:16"
-                 : "=&v"(wna), "=&v"(wnb)
-                 : "v"(wa_addr));
-    asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(tq[0]));
+    {
+        const float *wp = swsym + wa_addr;
+        asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=&s"(ws8) : "s"(wp));
+    }
+    // (a scalar load returns out of order: the first texel needs a full wait as well)
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(tq[0]), "+v"(tq[1]), "+v"(tqb[0]), "+v"(tqb[1]), "+s"(ws8));
     {
         const uint32_t tj = tq[0] & mask;
 #pragma unroll
@@ -1330,8 +1337,7 @@ __device__ __forceinline__ void jbf_tap_loop_rgb6(uint32_t lut_lane_addr, uint32
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(tq[1]), "+v"(tqb[0]), "+v"(tqb[1]), "+v"(wna), "+v"(wnb), "+v"(gg[0][0]),
-                   "+v"(gg[0][1]), "+v"(gg[0][2]), "+v"(gg[0][3]));
+                 : "+v"(gg[0][0]), "+v"(gg[0][1]), "+v"(gg[0][2]), "+v"(gg[0][3]));
 
 #define RF_TEXEL_OFFC(U) ((((U) + 2) & 3) * Q4 + (((U) + 2) >> 2))
     // Column step U: texel (both planes) of column +2 from TA/TB + offset, SAD + gathers of column
@@ -1366,8 +1372,8 @@ __device__ __forceinline__ void jbf_tap_loop_rgb6(uint32_t lut_lane_addr, uint32
                      : [ta] "v"(TA), [tb] "v"(TB), [off4] "n"((OFFT) * 4), [off2] "n"((OFFT) * 2), \
                        [mask] "v"(mask), [t1] "v"(tq[((U) + 1) & 3]), [t0] "v"(tq[(U)]),         \
                        [tb0] "v"(tqb[(U)]), [jc0] "v"(jc[0]), [jc1] "v"(jc[1]), [jc2] "v"(jc[2]), \
-                       [jc3] "v"(jc[3]), [wv0] "v"(wv[4 - (U)]), [wv1] "v"(wv[5 - (U)]),         \
-                       [wv2] "v"(wv[6 - (U)]), [wv3] "v"(wv[7 - (U)]), [g0] "v"(GA[0]),          \
+                       [jc3] "v"(jc[3]), [wv0] "s"(wv[4 - (U)]), [wv1] "s"(wv[5 - (U)]),         \
+                       [wv2] "s"(wv[6 - (U)]), [wv3] "s"(wv[7 - (U)]), [g0] "v"(GA[0]),          \
                        [g1] "v"(GA[1]), [g2] "v"(GA[2]), [g3] "v"(GA[3]));                       \
         asm volatile("v_lshl_add_u32 %[a0], %[a0], %[sh], %[la]\n\t"                             \
                      "v_add_f32 %[ws3], %[ws3], %[w3]\n\t"                                       \
@@ -1419,12 +1425,12 @@ __device__ __forceinline__ void jbf_tap_loop_rgb6(uint32_t lut_lane_addr, uint32
                        [s0] "v"(s0_), [s1] "v"(s1_), [s2] "v"(s2_));                             \
     }
 #define RF_C6_NOASM
-#define RF_C6_COMMA_W , "+v"(wna), "+v"(wnb)
-#define RF_C6_LOAD_WINDOW(ADDR)                                                                  \
-    asm volatile("ds_read_b128 %0, %2\n\t"                                                       \
-                 "ds_read_b128 %1, %2 offset:16"                                                 \
-                 : "=&v"(wna), "=&v"(wnb)                                                        \
-                 : "v"(ADDR));
+#define RF_C6_COMMA_W , "+s"(wn8)
+#define RF_C6_LOAD_WINDOW(IDX)                                                                   \
+    {                                                                                            \
+        const float *wp_ = swsym + (IDX);                                                        \
+        asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=&s"(wn8) : "s"(wp_));                      \
+    }
 
     for (int i = -radius; i <= radius; i++) {
         uint32_t ta_next, tb_next, wa_next;
@@ -1432,27 +1438,29 @@ __device__ __forceinline__ void jbf_tap_loop_rgb6(uint32_t lut_lane_addr, uint32
         row_addr(i < radius ? i + 1 : i, ta_next, tb_next, wa_next, ngroups_next);
         for (int gq = 0; gq < ngroups - 1; gq++) {
             float wv[8];
-            wv[0] = wna.x; wv[1] = wna.y; wv[2] = wna.z; wv[3] = wna.w;
-            wv[4] = wnb.x; wv[5] = wnb.y; wv[6] = wnb.z; wv[7] = wnb.w;
+            wv[0] = ws8[0]; wv[1] = ws8[1]; wv[2] = ws8[2]; wv[3] = ws8[3];
+            wv[4] = ws8[4]; wv[5] = ws8[5]; wv[6] = ws8[6]; wv[7] = ws8[7];
             RF_C6_STEP(0, gg[0], gg[1], ta, tb, RF_TEXEL_OFFC(0), RF_C6_NOASM, )
             RF_C6_STEP(1, gg[1], gg[0], ta, tb, RF_TEXEL_OFFC(1), RF_C6_NOASM, )
             RF_C6_STEP(2, gg[0], gg[1], ta, tb, RF_TEXEL_OFFC(2), RF_C6_NOASM, )
-            wa_addr -= 16;
+            wa_addr -= 4;
             RF_C6_STEP(3, gg[1], gg[0], ta, tb, RF_TEXEL_OFFC(3), RF_C6_LOAD_WINDOW(wa_addr),
                        RF_C6_COMMA_W)
+            ws8 = wn8;
             ta += 4;
             tb += 2;
         }
         {
             float wv[8];
-            wv[0] = wna.x; wv[1] = wna.y; wv[2] = wna.z; wv[3] = wna.w;
-            wv[4] = wnb.x; wv[5] = wnb.y; wv[6] = wnb.z; wv[7] = wnb.w;
+            wv[0] = ws8[0]; wv[1] = ws8[1]; wv[2] = ws8[2]; wv[3] = ws8[3];
+            wv[4] = ws8[4]; wv[5] = ws8[5]; wv[6] = ws8[6]; wv[7] = ws8[7];
             RF_C6_STEP(0, gg[0], gg[1], ta, tb, RF_TEXEL_OFFC(0), RF_C6_NOASM, )
             RF_C6_STEP(1, gg[1], gg[0], ta, tb, RF_TEXEL_OFFC(1), RF_C6_NOASM, )
             // the columns past the end of this row carry no weight: fetch the next row's first two
             RF_C6_STEP(2, gg[0], gg[1], ta_next, tb_next, 0, RF_C6_NOASM, )
             RF_C6_STEP(3, gg[1], gg[0], ta_next, tb_next, Q4, RF_C6_LOAD_WINDOW(wa_next),
                        RF_C6_COMMA_W)
+            ws8 = wn8;
         }
         ta = ta_next;
         tb = tb_next;
@@ -1751,7 +1759,7 @@ __global__ __launch_bounds__(1024) void jbf_tile64_kernel(
                                                      lds_addr(plane_b) + (uint32_t)tx * 2u, jc, 0u,
                                                      ty, radius, r4, sw_len, hwtab, sum, wsum);
             else
-                jbf_tap_loop_rgb6<CREP, TLW>(lut_lane_addr, sw_addr0,
+                jbf_tap_loop_rgb6<CREP, TLW>(lut_lane_addr, swsym,
                                              lds_addr(tile4) + (uint32_t)tx * 4u,
                                              lds_addr(plane_b) + (uint32_t)tx * 2u, jc, ty, radius,
                                              r4, sw_len, hwtab, sum, wsum);
@@ -1810,7 +1818,7 @@ __global__ __launch_bounds__(1024) void jbf_tile64_kernel(
                                                          lds_addr(plane_b) + (uint32_t)tx * 2u, jc, 0u,
                                                          ty, radius, r4, sw_len, hwtab, sum, wsum);
                 else
-                    jbf_tap_loop_rgb6<CREP, TLW>(lut_lane_addr, sw_addr0,
+                    jbf_tap_loop_rgb6<CREP, TLW>(lut_lane_addr, swsym,
                                                  lds_addr(tile4) + (uint32_t)tx * 4u,
                                                  lds_addr(plane_b) + (uint32_t)tx * 2u, jc, ty, radius,
                                                  r4, sw_len, hwtab, sum, wsum);
