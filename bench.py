@@ -327,16 +327,19 @@ def cpu_baseline(joint0, src0, sigma_color, sigma_spatial, target_s):
 
 def valu_roofline(n, h, w, radius, kernel_ms, taps_per_launch, clock_mhz=None):
     """Issue-floor time of the launch = column steps x 26 instructions x 2 cycles / (1024 SIMDs
-    x shader clock).  Column steps per wave follow the kernel's row walk: per tap row, groups of 4
-    columns covering -hw4 .. hw4+3 (hw = half-width of the disk on that row, hw4 = hw rounded up
-    to a multiple of 4).  The clock is the one measured under this launch (`measured_clock_mhz`:
+    x shader clock).  Column steps per wave follow the kernel's row walk: per tap row, whole groups
+    of 4 columns from the even column -hws on, covering -hw .. hw+3 (hw = half-width of the disk on
+    that row, hws = hw rounded up to even; until round 5 rows started at a multiple of 4: 3,764
+    instead of 3,664 steps per output quad at radius 33; the four outputs of a lane need 3,610).  The
+    26 are the step's tap arithmetic; the loop spends 2 more per group of 4 steps on its two texel
+    addresses.  The clock is the one measured under this launch (`measured_clock_mhz`:
     a one-wave probe on a second stream, s_memtime over s_memrealtime); `floor_ms_at_2400mhz` is
     the same floor at the 2.4 GHz peak clock of MI355X_MICROARCH.md."""
     steps_per_wave = 0
     for i in range(-radius, radius + 1):
         hw = int((radius * radius - i * i) ** 0.5)
-        hw4 = (hw + 3) & ~3
-        steps_per_wave += 4 * (hw4 // 2 + 1)
+        hws = (hw + 1) & ~1
+        steps_per_wave += (hws + hw + 4 + 3) & ~3
     tiles = n * ((w + 63) // 64) * ((h + 63) // 64)
     wave_steps = tiles * 16 * steps_per_wave          # 16 waves per 64x64 tile
     cycles = wave_steps * 26 * 2 / 1024.0

@@ -1003,16 +1003,29 @@ __device__ __forceinline__ void jbf_tap_loop_grey4_la2(uint32_t lut_lane_addr,
     constexpr int SHIFT = LUTREP == 32 ? 7 : LUTREP == 16 ? 6 : LUTREP == 8 ? 5 : 4;
     static_assert(LUTREP == 32 || LUTREP == 16 || LUTREP == 8 || LUTREP == 4, "LUT replicas");
     static_assert(3 * Q4 + 1 <= 255, "ds_read2_b32 offsets are 8 bits");
+    static_assert(TLW % 4 == 0, "column-interleaved planes");
     uint32_t mask = 0x00ffffffu;
     asm volatile("" : "+v"(mask));  // keep the mask in a VGPR (a literal operand is full-pipe)
 
-    auto row_addr = [&](int i, uint32_t &ta_out, uint32_t &wa_out, int &ngroups_out) {
-        const int hw = hwtab[i + radius];
-        const int hw4 = (hw + 3) & ~3;
+    // A tap row of half-width hw serves the lane's four outputs from the 2 hw + 4 columns -hw .. hw + 3.
+    // The row starts at the EVEN column -hws (hws = hw rounded up to even) and runs whole groups of four
+    // from there: at most two columns of zero weight per row (round 4 started at a multiple of four, the
+    // alignment its ds_read_b128 weight windows needed: up to six; 3,664 column steps instead of 3,764
+    // per output quad at radius 33).  A row that starts in the middle of a quad of the column-
+    // interleaved tile (phase 1) finds columns (0, 1) of a group in planes 2, 3 and columns (2, 3) in
+    // planes 0, 1 of the next quad: each of the two pair reads has its own address register.
+    const uint32_t lane_row0 = tile_lane_addr + (uint32_t)(ty * TLW * 4);  // the lane's part of an address
+    auto row_addr = [&](int i, int hw, uint32_t &ta_out, uint32_t &tb_out, uint32_t &wa_out,
+                        int &ngroups_out) {
+        const int hws = (hw + 1) & ~1;
         const int ai = i < 0 ? -i : i;
-        ta_out = tile_lane_addr + (uint32_t)(((ty + i + radius) * TLW + ((r4 - hw4) >> 2)) * 4);
-        wa_out = (uint32_t)(ai * sw_len + (r4 + 8) + hw4 - 4);  // index of the first window's first weight
-        ngroups_out = (hw4 >> 1) + 1;
+        const int c0 = r4 - hws;  // first column, relative to the lane's quad origin
+        const int quad = (i + radius) * TLW + (c0 >> 2);
+        const int phase = (c0 >> 1) & 1;
+        ta_out = lane_row0 + (uint32_t)((quad + (phase ? 2 * Q4 : 0)) * 4);
+        tb_out = lane_row0 + (uint32_t)((quad + (phase ? 1 : 2 * Q4)) * 4);
+        wa_out = (uint32_t)(ai * sw_len + (r4 + 8) + hws - 4);  // index of the first window's first weight
+        ngroups_out = (hws + hw + 4 + 3) >> 2;
     };
 
     uint2v tp[2];        // texel pairs: tp[0] = columns (0, 1), tp[1] = columns (2, 3) of a group
@@ -1026,15 +1039,25 @@ __device__ __forceinline__ void jbf_tap_loop_grey4_la2(uint32_t lut_lane_addr,
     float8v ws8, wn8;    // this group's window, the next group's
     float gg[4][kPix];   // gg[u]: LUT values of the group's column u (in flight, then consumed at step u)
     float sv[4];         // sv[u]: src value of column u as float
-    uint32_t ta, wa_addr;
+    uint32_t ta, tb, wa_addr;
     int ngroups;
-    row_addr(-radius, ta, wa_addr, ngroups);
+    row_addr(-radius, 0, ta, tb, wa_addr, ngroups);  // (the top row of the disk: half-width 0)
+    // The half-width of row i + 1 is needed during row i (its last group reads ahead into row i + 1).
+    // A load the compiler issues gets its wait - a full one - at the first use, in the middle of a row
+    // with four gathers in flight: one pipeline drain per row.  So the value is requested a row early
+    // by hand (hw_ahead, at the top of row i - 1) and taken over at the top of row i: every group has a
+    // full wait in the middle of its step 3 (RF_L2_WAIT_WINDOW), a row at least one group.
+    int hw_ahead;
+    {
+        const int *hp = hwtab + 1;
+        asm volatile("s_load_dword %0, %1, 0x0" : "=s"(hw_ahead) : "s"(hp));  // (waited for below)
+    }
     // prologue: both texel pairs and the weight window of the first group, gathers and src values of
     // its columns 0 and 1
-    asm volatile("ds_read2_b32 %0, %2 offset1:%3\n\t"
-                 "ds_read2_b32 %1, %2 offset0:%4 offset1:%5"
+    asm volatile("ds_read2_b32 %0, %2 offset1:%4\n\t"
+                 "ds_read2_b32 %1, %3 offset1:%4"
                  : "=&v"(tp[0]), "=&v"(tp[1])
-                 : "v"(ta), "n"(Q4), "n"(2 * Q4), "n"(3 * Q4));
+                 : "v"(ta), "v"(tb), "n"(Q4));
     {
         const float *wp = swsym + wa_addr;
         asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=&s"(ws8) : "s"(wp));
@@ -1059,7 +1082,12 @@ __device__ __forceinline__ void jbf_tap_loop_grey4_la2(uint32_t lut_lane_addr,
 
 #define RF_L2_TQ(U) tp[((U) & 3) >> 1][(U) & 1]
     // even steps read a texel pair of the NEXT group (or of the next row's first group): step 0 its
-    // columns (0, 1) into tp[0], step 2 its columns (2, 3) into tp[1]
+    // columns (0, 1) into tp[0], step 2 its columns (2, 3) into tp[1].  Where a pair sits depends on the
+    // phase of its row: each of the two reads has its own address register (ta: columns (0, 1), tb:
+    // columns (2, 3)), set per row, and the ds_read2 offsets are the same for both phases - one v_add
+    // per group more, and no branch in the loop (at a join the compiler may move registers, and
+    // gathers are in flight at every group end; issuing the read twice under complementary EXEC masks
+    // was measured too: the three EXEC writes per read cost more than the shorter rows return)
 #define RF_L2_TNOUT(U) RF_L2_TNOUT_##U
 #define RF_L2_TNOUT_0 [tn] "=&v"(tp[0]),
 #define RF_L2_TNOUT_2 [tn] "=&v"(tp[1]),
@@ -1067,12 +1095,12 @@ __device__ __forceinline__ void jbf_tap_loop_grey4_la2(uint32_t lut_lane_addr,
 #define RF_L2_TNOUT_3
 #define RF_L2_READ(U) RF_L2_READ_##U
 #define RF_L2_READ_0 "ds_read2_b32 %[tn], %[ta] offset0:%[o0] offset1:%[o1]\n\t"
-#define RF_L2_READ_2 "ds_read2_b32 %[tn], %[ta] offset0:%[o0] offset1:%[o1]\n\t"
+#define RF_L2_READ_2 RF_L2_READ_0
 #define RF_L2_READ_1 ""
 #define RF_L2_READ_3 ""
     // Step U of a group, first half: [texel pair]; SADs of column U + 2 interleaved with the weights
     // of column U (GA = its gathered LUT values); src value of column U + 2.
-#define RF_L2_PART1A(U, GA, GB, TA, O0, O1)                                                         \
+#define RF_L2_PART1A(U, GA, GB, TA, O0, O1)                                                                       \
     float w0_, w1_, w2_, w3_;                                                                    \
     uint32_t tj_;                                                                                \
     asm volatile(RF_L2_READ(U)                                                                   \
@@ -1094,7 +1122,7 @@ __device__ __forceinline__ void jbf_tap_loop_grey4_la2(uint32_t lut_lane_addr,
                    [jc1] "v"(jc[1]), [jc2] "v"(jc[2]), [jc3] "v"(jc[3]), [wv0] "s"(wv[4 - (U)]), \
                    [wv1] "s"(wv[5 - (U)]), [wv2] "s"(wv[6 - (U)]), [wv3] "s"(wv[7 - (U)]),       \
                    [g0] "v"(GA[0]), [g1] "v"(GA[1]), [g2] "v"(GA[2]), [g3] "v"(GA[3]));
-#define RF_L2_PART1A_J1(U, GA, GB, TA, O0, O1)                                                      \
+#define RF_L2_PART1A_J1(U, GA, GB, TA, O0, O1)                                                                    \
     float w0_, w1_, w2_, w3_;                                                                    \
     uint32_t tj_;                                                                                \
     asm volatile(RF_L2_READ(U)                                                                   \
@@ -1169,17 +1197,24 @@ __device__ __forceinline__ void jbf_tap_loop_grey4_la2(uint32_t lut_lane_addr,
                  : [s] "v"(sv[(U)]));
     // (function-like so that the names travel through the macro levels unexpanded)
 #define RF_L2_NONE()
-    // (the last step of a ROW waits for everything, the gathers of the next row's column 1 included:
-    //  the compiler is free to move registers around at the row loop's back edge - a variant of this
-    //  loop got a v_mov of a gather register whose read was in flight there, found by
-    //  tests/test_cabi.py on the machine code - and a row is long enough not to notice one full wait)
-#define RF_L2_COMMA_ALL() , "+v"(gg[1][0]), "+v"(gg[1][1]), "+v"(gg[1][2]), "+v"(gg[1][3])
+    // (The last step of a row waits like any other: four gathers stay in flight across the row loop's
+    //  back edge, where the compiler writes code of its own - the next row's addresses.  That it moves
+    //  none of the registers in flight there is checked on the machine code, along every path of the
+    //  control-flow graph: tests/test_cabi.py.  A variant of this loop once got such a v_mov; a full wait
+    //  at the row end, which this loop had until the check walked branches, costs 0.3 %.)
     // ... which is waited for in the middle of step 3, where a full wait costs next to nothing: nothing
     // is in flight there but the gathers of step 2, issued a whole step ago, and the window itself,
     // requested three steps ago (step 3 reads no texel pair); step 3's own gathers follow the wait
 #define RF_L2_WAIT_WINDOW                                                                        \
     asm volatile("s_waitcnt lgkmcnt(0)"                                                          \
-                 : "+s"(wn8), "+v"(gg[0][0]), "+v"(gg[0][1]), "+v"(gg[0][2]), "+v"(gg[0][3]));
+                 : "+v"(gg[0][0]), "+v"(gg[0][1]), "+v"(gg[0][2]), "+v"(gg[0][3]));
+    // the window changes hands after the group: the empty statement is ordered behind the wait above (both
+    // are volatile) and keeps the copy behind itself.  (Load and hand-over stand outside the two forms of
+    // a group so that no SGPR tuple meets itself at the join of a branch: the backend puts such a merge
+    // into VGPRs and then cannot give it back to an "s" operand.)
+#define RF_L2_HAND_OVER                                                                          \
+    asm volatile("" : "+s"(wn8));                                                                \
+    ws8 = wn8;
     // the next group's window: a scalar load of 8 floats from the table in global memory (scalar cache)
 #define RF_L2_LOAD_WINDOW(IDX)                                                                   \
     {                                                                                            \
@@ -1190,50 +1225,64 @@ __device__ __forceinline__ void jbf_tap_loop_grey4_la2(uint32_t lut_lane_addr,
     // or the next row's first one), with the pair offsets P0A/P0B (columns 0, 1) and P2A/P2B (2, 3);
     // WLOAD = the statement that loads the next weight window (after the window's last use in step
     // 3, before that step's gathers)
-#define RF_L2_GROUP(P1A, P1B, NB, P0A, P0B, P2A, P2B, WLOAD, WOPS, WAIT3)                         \
+#define RF_L2_GROUP(P1A, P1B, NA, NB, PA, PB, WOPS, WAIT3)                                        \
     {                                                                                            \
-        float wv[8];                                                                             \
-        wv[0] = ws8[0]; wv[1] = ws8[1]; wv[2] = ws8[2]; wv[3] = ws8[3];                          \
-        wv[4] = ws8[4]; wv[5] = ws8[5]; wv[6] = ws8[6]; wv[7] = ws8[7];                          \
-        WLOAD                                                                                    \
         {                                                                                        \
-            P1A(0, gg[0], gg[2], NB, P0A, P0B)                                                   \
+            P1A(0, gg[0], gg[2], NA, PA, PB)                                               \
             P1B(gg[2])                                                                           \
             RF_L2_PART2(0, tp[0], gg[1], RF_L2_NONE, "4")                                                  \
         }                                                                                        \
         {                                                                                        \
-            P1A(1, gg[1], gg[3], NB, 0, 0)                                                       \
+            P1A(1, gg[1], gg[3], NA, 0, 0)                                                   \
             P1B(gg[3])                                                                           \
             RF_L2_PART2(1, tp[0], gg[2], RF_L2_NONE, "4")                                                  \
         }                                                                                        \
         {                                                                                        \
-            P1A(2, gg[2], gg[0], NB, P2A, P2B)                                                   \
+            P1A(2, gg[2], gg[0], NB, PA, PB)                                               \
             P1B(gg[0])                                                                           \
             RF_L2_PART2(2, tp[1], gg[3], RF_L2_NONE, "4")                                                  \
         }                                                                                        \
         {                                                                                        \
-            P1A(3, gg[3], gg[1], NB, 0, 0)                                                       \
+            P1A(3, gg[3], gg[1], NB, 0, 0)                                                   \
             RF_L2_WAIT_WINDOW                                                                    \
             P1B(gg[1])                                                                           \
             RF_L2_PART2(3, tp[1], gg[0], WOPS, WAIT3)                                            \
         }                                                                                        \
-        ws8 = wn8;                                                                               \
     }
 #define RF_L2_ROW_LOOP(P1A, P1B)                                                                  \
     for (int i = -radius; i <= radius; i++) {                                                     \
-        uint32_t ta_next, wa_next;                                                                \
+        uint32_t ta_next, tb_next, wa_next;                                                       \
         int ngroups_next;                                                                         \
-        row_addr(i < radius ? i + 1 : i, ta_next, wa_next, ngroups_next);                         \
-        for (int gq = 0; gq < ngroups - 1; gq++) {                                                \
-            RF_L2_GROUP(P1A, P1B, ta, 1, Q4 + 1, 2 * Q4 + 1, 3 * Q4 + 1,                          \
-                        wa_addr -= 4; RF_L2_LOAD_WINDOW(wa_addr), RF_L2_NONE, "4")                \
-            ta += 4;                                                                              \
+        asm volatile("" : "+s"(hw_ahead)); /* behind the full waits of the row before */           \
+        row_addr(i < radius ? i + 1 : i, __builtin_amdgcn_readfirstlane(hw_ahead), ta_next,       \
+                 tb_next, wa_next, ngroups_next);                                                 \
+        {                                                                                         \
+            const int *hp_ = hwtab + ((i + 2 < radius ? i + 2 : radius) + radius);                \
+            asm volatile("s_load_dword %0, %1, 0x0" : "=s"(hw_ahead) : "s"(hp_));                 \
         }                                                                                         \
-        RF_L2_GROUP(P1A, P1B, ta_next, 0, Q4, 2 * Q4, 3 * Q4, RF_L2_LOAD_WINDOW(wa_next),         \
-                    RF_L2_COMMA_ALL, "0")                                                         \
+        for (int gq = 0; gq < ngroups - 1; gq++) {                                                \
+            float wv[8];                                                                          \
+            wv[0] = ws8[0]; wv[1] = ws8[1]; wv[2] = ws8[2]; wv[3] = ws8[3];                       \
+            wv[4] = ws8[4]; wv[5] = ws8[5]; wv[6] = ws8[6]; wv[7] = ws8[7];                       \
+            wa_addr -= 4;                                                                         \
+            RF_L2_LOAD_WINDOW(wa_addr)                                                            \
+            RF_L2_GROUP(P1A, P1B, ta, tb, 1, Q4 + 1, RF_L2_NONE, "4")                             \
+            RF_L2_HAND_OVER                                                                       \
+            ta += 4;                                                                              \
+            tb += 4;                                                                              \
+        }                                                                                         \
+        {                                                                                         \
+            float wv[8];                                                                          \
+            wv[0] = ws8[0]; wv[1] = ws8[1]; wv[2] = ws8[2]; wv[3] = ws8[3];                       \
+            wv[4] = ws8[4]; wv[5] = ws8[5]; wv[6] = ws8[6]; wv[7] = ws8[7];                       \
+            RF_L2_LOAD_WINDOW(wa_next)                                                            \
+            RF_L2_GROUP(P1A, P1B, ta_next, tb_next, 0, Q4, RF_L2_NONE, "4")                       \
+            RF_L2_HAND_OVER                                                                       \
+        }                                                                                         \
         ta = ta_next;                                                                             \
         wa_addr = wa_next;                                                                        \
         ngroups = ngroups_next;                                                                   \
+        tb = tb_next;                                                                             \
     }
     if constexpr (J1) {
         RF_L2_ROW_LOOP(RF_L2_PART1A_J1, RF_L2_PART1B_J1)
@@ -1245,12 +1294,12 @@ __device__ __forceinline__ void jbf_tap_loop_grey4_la2(uint32_t lut_lane_addr,
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(gg[0][0]), "+v"(gg[0][1]), "+v"(gg[0][2]), "+v"(gg[0][3]), "+v"(gg[1][0]),
                    "+v"(gg[1][1]), "+v"(gg[1][2]), "+v"(gg[1][3]), "+v"(tp[0]), "+v"(tp[1]),
-                   "+s"(ws8), "+s"(wn8));
+                   "+s"(ws8), "+s"(wn8), "+s"(hw_ahead));
 #undef RF_L2_ROW_LOOP
 #undef RF_L2_GROUP
 #undef RF_L2_LOAD_WINDOW
 #undef RF_L2_WAIT_WINDOW
-#undef RF_L2_COMMA_ALL
+#undef RF_L2_HAND_OVER
 #undef RF_L2_NONE
 #undef RF_L2_PART2
 #undef RF_L2_PART1B_J1

@@ -22,6 +22,7 @@ def test_valu_roofline_object():
     # 4,489-tap square/4, plus the zero-weight padding columns
     per_wave = obj["column_steps_per_launch"] / (256 * 30 * 17 * 16)
     assert 3409 / 4 < per_wave < 67 * (67 + 11) / 1 and per_wave % 4 == 0
+    assert per_wave == 3664  # rows start at an even column (3,764 when they started at a multiple of 4)
     assert np.isclose(obj["taps_per_s"], taps / 0.265)
 
 

@@ -98,15 +98,22 @@ def _disassembly(tmp_path_factory):
     for obj in glob.glob(copy + ".*gfx950"):
         name = None
         for line in subprocess.check_output([tool, "-d", obj]).decode().splitlines():
-            m = re.match(r"^[0-9a-f]+ <([^>]+)>:", line)
+            m = re.match(r"^([0-9a-f]+) <([^>]+)>:", line)
             if m:
-                name = m.group(1)
+                name = m.group(2)
                 funcs[name] = []
+                _FLOW[name] = {"start": int(m.group(1), 16), "addr": [], "target": []}
                 continue
-            m = re.match(r"^\s+([a-z_0-9]+)\s*([^/]*)", line)
+            m = re.match(r"^\s+([a-z_0-9]+)\s*([^/]*)(?://\s*([0-9A-Fa-f]+):)?", line)
             if m and name is not None:
                 funcs[name].append((m.group(1), m.group(2).strip()))
+                t = re.search(r"<[^>]*\+0x([0-9a-f]+)>\s*$", line)
+                _FLOW[name]["addr"].append(int(m.group(3), 16) if m.group(3) else None)
+                _FLOW[name]["target"].append(int(t.group(1), 16) if t else None)
     return funcs
+
+
+_FLOW = {}   # per function: start address, address of every instruction, branch targets (offsets)
 
 
 @pytest.fixture(scope="module")
@@ -159,43 +166,63 @@ def _vgprs(text):
 def test_lds_reads_in_flight_are_not_touched_before_their_wait(disassembly):
     """The joint bilateral's asm tap loops issue LDS reads in one inline-asm statement and wait for
     them in a later one - the round-5 loop keeps four gathers in flight ACROSS a column step
-    (`s_waitcnt lgkmcnt(4)`) - and the compiler does not know they are in flight: nothing between a
-    `ds_read*` and the wait that covers it may read or write its destination VGPRs (a register move
-    would copy a stale value, a re-use would be overwritten when the data lands).  LDS operations of
-    a wave return in order, so `lgkmcnt(n)` leaves at most the n youngest reads pending (scalar loads
-    share the counter and only make a wait stricter).  Checked on the machine code of every
-    joint-bilateral kernel, function ends included (no read may still be pending at `s_endpgm`)."""
+    (`s_waitcnt lgkmcnt(4)`), across the groups of a row and across rows - and the compiler does not
+    know they are in flight: nothing between a `ds_read*` and the wait that covers it may read or write
+    its destination VGPRs (a register move would copy a stale value, a re-use would be overwritten
+    when the data lands).  LDS operations of a wave return in order, so `lgkmcnt(n)` leaves at most the
+    n youngest reads pending (scalar loads share the counter and only make a wait stricter).  Checked
+    on the machine code of every joint-bilateral kernel along every path of its control-flow graph
+    (both sides of every branch, loop back edges included: the compiler writes a row loop's header
+    itself), function ends included (no read may still be pending at `s_endpgm`)."""
     checked = kernels = 0
     for name, insts in disassembly.items():
         if "jbf_" not in name or "f32" in name:
             continue
         kernels += 1
-        pending = []                      # destination register sets, oldest first
-        for op, args in insts:
-            if op.startswith("ds_"):     # every LDS operation takes a place in the in-order queue
-                reads = op.startswith("ds_read") or op.startswith("ds_load") or "_rtn" in op
-                dst = _vgprs(args.split(",")[0]) if reads else set()
-                busy = set().union(*pending) if pending else set()
-                assert not (_vgprs(args) & busy), (name, op, args)
-                pending.append(dst)
-                checked += 1 if reads else 0
-                continue
-            if op == "s_waitcnt":
-                m = re.search(r"lgkmcnt\((\d+)\)", args)
-                if m:
-                    keep = int(m.group(1))
-                    pending = pending[len(pending) - keep:] if keep < len(pending) else pending
-                    if keep == 0:
-                        pending = []
-                continue
-            if op in ("s_endpgm", "s_setpc_b64"):
-                assert not pending, (name, op, "LDS reads still in flight at the end")
-                continue
-            if op.startswith("s_cbranch") or op == "s_branch" or op == "s_barrier":
-                continue                  # (control flow: the loops are checked as straight-line text)
-            if pending:
-                busy = set().union(*pending)
-                assert not (_vgprs(args) & busy), (name, op, args, sorted(busy)[:8])
+        flow = _FLOW[name]
+        index_of = {a: i for i, a in enumerate(flow["addr"]) if a is not None}
+        seen = set()
+        work = [(0, ())]                  # (instruction index, destination register sets, oldest first)
+        while work:
+            i, pending = work.pop()
+            while i < len(insts):
+                key = (i, pending)
+                if key in seen:
+                    break
+                seen.add(key)
+                op, args = insts[i]
+                busy = frozenset().union(*pending) if pending else frozenset()
+                if op.startswith("ds_"):     # every LDS operation takes a place in the in-order queue
+                    reads = op.startswith("ds_read") or op.startswith("ds_load") or "_rtn" in op
+                    dst = frozenset(_vgprs(args.split(",")[0])) if reads else frozenset()
+                    # (its destination may be that of an older read: returns are in order)
+                    srcs = args.split(",", 1)[1] if reads and "," in args else args
+                    assert not (_vgprs(srcs) & busy), (name, op, args)
+                    pending = pending + (dst,)
+                    checked += 1 if reads else 0
+                elif op == "s_waitcnt":
+                    m = re.search(r"lgkmcnt\((\d+)\)", args)
+                    if m:
+                        keep = int(m.group(1))
+                        pending = pending[len(pending) - keep:] if 0 < keep < len(pending) else \
+                            (() if keep == 0 else pending)
+                elif op in ("s_endpgm", "s_setpc_b64"):
+                    assert not pending, (name, op, "LDS reads still in flight at the end")
+                    break
+                elif op.startswith("s_cbranch") or op == "s_branch":
+                    target = flow["target"][i]
+                    assert target is not None and flow["start"] + target in index_of, (name, op, args)
+                    work.append((index_of[flow["start"] + target], pending))
+                    if op == "s_branch":
+                        break
+                elif op != "s_barrier":
+                    assert not (_vgprs(args) & busy), (name, op, args, sorted(busy)[:8])
+                # (the counter has 4 bits: with 15 operations outstanding the next one waits for the oldest;
+                #  a write at the head of the queue pins no register)
+                pending = pending[-15:]
+                while pending and not pending[0]:
+                    pending = pending[1:]
+                i += 1
     assert kernels >= 8 and checked > 2000, (kernels, checked)
 
 
