@@ -106,6 +106,22 @@ constexpr int kIters = 4096 * 32;
 #define A_ONLY_SAD16(unused_) asm volatile(F_SAD(0) F_SAD(1) F_SAD(2) F_SAD(3) F_SAD(4) F_SAD(5) F_SAD(6) F_SAD(7) F_SAD(0) F_SAD(1) F_SAD(2) F_SAD(3) F_SAD(4) F_SAD(5) F_SAD(6) F_SAD(7) : REGS);
 #define A_ONLY_MUL16(unused_) asm volatile(S_MUL(0) S_MUL(1) S_MUL(2) S_MUL(3) S_MUL(4) S_MUL(5) S_MUL(6) S_MUL(7) S_MUL(0) S_MUL(1) S_MUL(2) S_MUL(3) S_MUL(4) S_MUL(5) S_MUL(6) S_MUL(7) : REGS);
 
+// 24-bit integer multiplies (stage 1's products: one v_mad_i32_i24 each, or a multiply and an add?)
+#define F_MUL24(x) "v_mul_u32_u24 %" #x ", %" #x ", %8\n"
+#define F_MULI24(x) "v_mul_i32_i24 %" #x ", %" #x ", %8\n"
+#define S_ADDU(x) "v_add_u32 %" #x ", %8, %" #x "\n"
+#define A_MUL24MUL_INTER(unused_) asm volatile(F_MUL24(0) S_MUL(1) F_MUL24(2) S_MUL(3) F_MUL24(4) S_MUL(5) F_MUL24(6) S_MUL(7) F_MUL24(1) S_MUL(0) F_MUL24(3) S_MUL(2) F_MUL24(5) S_MUL(4) F_MUL24(7) S_MUL(6) : REGS);
+#define A_MULI24ADD_INTER(unused_) asm volatile(F_MULI24(0) S_ADDU(1) F_MULI24(2) S_ADDU(3) F_MULI24(4) S_ADDU(5) F_MULI24(6) S_ADDU(7) F_MULI24(1) S_ADDU(0) F_MULI24(3) S_ADDU(2) F_MULI24(5) S_ADDU(4) F_MULI24(7) S_ADDU(6) : REGS);
+#define A_ONLY_MUL24(unused_) asm volatile(F_MUL24(0) F_MUL24(1) F_MUL24(2) F_MUL24(3) F_MUL24(4) F_MUL24(5) F_MUL24(6) F_MUL24(7) F_MUL24(0) F_MUL24(1) F_MUL24(2) F_MUL24(3) F_MUL24(4) F_MUL24(5) F_MUL24(6) F_MUL24(7) : REGS);
+#define A_ONLY_MAD24(unused_) asm volatile(F_MAD(0) F_MAD(1) F_MAD(2) F_MAD(3) F_MAD(4) F_MAD(5) F_MAD(6) F_MAD(7) F_MAD(0) F_MAD(1) F_MAD(2) F_MAD(3) F_MAD(4) F_MAD(5) F_MAD(6) F_MAD(7) : REGS);
+// the move form of a DPP step (v_mov_b32_dpp + a plain add instead of v_add_u32_dpp)
+#define F_DPPMOV(x, y) "v_mov_b32_dpp %" #y ", %" #x " row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+#define A_DPPMOVSUB_INTER(unused_) asm volatile("s_nop 1\n" F_DPPMOV(0, 1) S_SUB(2) F_DPPMOV(2, 3) S_SUB(4) F_DPPMOV(4, 5) S_SUB(6) F_DPPMOV(6, 7) S_SUB(0) F_DPPMOV(1, 0) S_SUB(3) F_DPPMOV(3, 2) S_SUB(5) F_DPPMOV(5, 4) S_SUB(7) F_DPPMOV(7, 6) S_SUB(1) : REGS);
+KERNEL(k_mul24_mul_interleaved, A_MUL24MUL_INTER)
+KERNEL(k_muli24_addu_interleaved, A_MULI24ADD_INTER)
+KERNEL(k_only_mul24, A_ONLY_MUL24)
+KERNEL(k_only_mad24, A_ONLY_MAD24)
+KERNEL(k_dppmov_sub_interleaved, A_DPPMOVSUB_INTER)
 KERNEL(k_sadmul_interleaved, A_SADMUL_INTER)
 KERNEL(k_sadmul_clustered8, A_SADMUL_CLUST)
 KERNEL(k_dppsub_interleaved, A_DPPSUB_INTER)
@@ -193,5 +209,10 @@ int main()
     RUN(k_split_waves, 4);
     RUN(k_only_sad, 4);
     RUN(k_only_mul, 4);
+    RUN(k_mul24_mul_interleaved, 4);
+    RUN(k_muli24_addu_interleaved, 4);
+    RUN(k_only_mul24, 4);
+    RUN(k_only_mad24, 4);
+    RUN(k_dppmov_sub_interleaved, 4);
     return 0;
 }
