@@ -1341,16 +1341,26 @@ __device__ __forceinline__ void jbf_tap_loop_rgb6(uint32_t lut_lane_addr,
     uint32_t mask = 0x00ffffffu;
     asm volatile("" : "+v"(mask));  // keep the mask in a VGPR (a literal operand is full-pipe)
 
-    auto row_addr = [&](int i, uint32_t &ta_out, uint32_t &tb_out, uint32_t &wa_out,
-                        int &ngroups_out) {
+    // Rows start at the even column -hws and run whole groups of four, as in jbf_tap_loop_grey4_la2.
+    // Steps 0, 1 of a group read columns 2, 3 of the group through the address pair (ta, tb), steps 2, 3
+    // read columns 0, 1 of the NEXT group through (ta2, tb2) - the row's phase decides which planes of
+    // the column-interleaved tile those are, the offsets in the instructions do not change.
+    auto row_addr = [&](int i, uint32_t &ta_out, uint32_t &tb_out, uint32_t &ta2_out,
+                        uint32_t &tb2_out, uint32_t &wa_out, int &ngroups_out) {
         const int hw = hwtab[i + radius];
-        const int hw4 = (hw + 3) & ~3;
+        const int hws = (hw + 1) & ~1;
         const int ai = i < 0 ? -i : i;
-        const uint32_t texel0 = (uint32_t)((ty + i + radius) * TLW + ((r4 - hw4) >> 2));
-        ta_out = tile_lane_addr + texel0 * 4;
-        tb_out = plane_b_lane_addr + texel0 * 2;
-        wa_out = (uint32_t)(ai * sw_len + (r4 + 8) + hw4 - 4);  // index of the first window's first weight
-        ngroups_out = (hw4 >> 1) + 1;
+        const int c0 = r4 - hws;  // first column, relative to the lane's quad origin
+        const uint32_t quad = (uint32_t)((ty + i + radius) * TLW + (c0 >> 2));
+        const bool phase = ((c0 >> 1) & 1) != 0;
+        const uint32_t q23 = quad + (phase ? 1u : 2u * Q4);  // columns 2, 3 of the row's first group
+        const uint32_t q01 = quad + (phase ? 2u * Q4 : 0u);  // columns 0, 1 of the row's first group
+        ta_out = tile_lane_addr + q23 * 4;
+        tb_out = plane_b_lane_addr + q23 * 2;
+        ta2_out = tile_lane_addr + q01 * 4;
+        tb2_out = plane_b_lane_addr + q01 * 2;
+        wa_out = (uint32_t)(ai * sw_len + (r4 + 8) + hws - 4);  // index of the first window's first weight
+        ngroups_out = (hws + hw + 4 + 3) >> 2;
     };
 
     uint32_t tq[4], tqb[4];
@@ -1360,16 +1370,16 @@ __device__ __forceinline__ void jbf_tap_loop_rgb6(uint32_t lut_lane_addr,
     typedef float float8v __attribute__((ext_vector_type(8)));
     float8v ws8, wn8;
     float gg[2][kPix];
-    uint32_t ta, tb, wa_addr;
+    uint32_t ta, tb, ta2, tb2, wa_addr;
     int ngroups;
-    row_addr(-radius, ta, tb, wa_addr, ngroups);
+    row_addr(-radius, ta, tb, ta2, tb2, wa_addr, ngroups);
     // prologue of the first tap row (later rows get theirs from the last group of the row before)
     asm volatile("ds_read_b32 %0, %4\n\t"
                  "ds_read_b32 %1, %4 offset:%6\n\t"
                  "ds_read_u16 %2, %5\n\t"
                  "ds_read_u16 %3, %5 offset:%7"
                  : "=&v"(tq[0]), "=&v"(tq[1]), "=&v"(tqb[0]), "=&v"(tqb[1])
-                 : "v"(ta), "v"(tb), "n"(Q4 * 4), "n"(Q4 * 2));
+                 : "v"(ta2), "v"(tb2), "n"(Q4 * 4), "n"(Q4 * 2));
     {
         const float *wp = swsym + wa_addr;
         asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=&s"(ws8) : "s"(wp));
@@ -1388,7 +1398,6 @@ __device__ __forceinline__ void jbf_tap_loop_rgb6(uint32_t lut_lane_addr,
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(gg[0][0]), "+v"(gg[0][1]), "+v"(gg[0][2]), "+v"(gg[0][3]));
 
-#define RF_TEXEL_OFFC(U) ((((U) + 2) & 3) * Q4 + (((U) + 2) >> 2))
     // Column step U: texel (both planes) of column +2 from TA/TB + offset, SAD + gathers of column
     // +1, accumulation of column +0.  GA = gathers consumed, GB = gathers issued (their registers
     // hold alpha, then the LDS address, then the LUT value).
@@ -1482,37 +1491,41 @@ __device__ __forceinline__ void jbf_tap_loop_rgb6(uint32_t lut_lane_addr,
     }
 
     for (int i = -radius; i <= radius; i++) {
-        uint32_t ta_next, tb_next, wa_next;
+        uint32_t ta_next, tb_next, ta2_next, tb2_next, wa_next;
         int ngroups_next;
-        row_addr(i < radius ? i + 1 : i, ta_next, tb_next, wa_next, ngroups_next);
+        row_addr(i < radius ? i + 1 : i, ta_next, tb_next, ta2_next, tb2_next, wa_next, ngroups_next);
         for (int gq = 0; gq < ngroups - 1; gq++) {
             float wv[8];
             wv[0] = ws8[0]; wv[1] = ws8[1]; wv[2] = ws8[2]; wv[3] = ws8[3];
             wv[4] = ws8[4]; wv[5] = ws8[5]; wv[6] = ws8[6]; wv[7] = ws8[7];
-            RF_C6_STEP(0, gg[0], gg[1], ta, tb, RF_TEXEL_OFFC(0), RF_C6_NOASM, )
-            RF_C6_STEP(1, gg[1], gg[0], ta, tb, RF_TEXEL_OFFC(1), RF_C6_NOASM, )
-            RF_C6_STEP(2, gg[0], gg[1], ta, tb, RF_TEXEL_OFFC(2), RF_C6_NOASM, )
+            RF_C6_STEP(0, gg[0], gg[1], ta, tb, 0, RF_C6_NOASM, )
+            RF_C6_STEP(1, gg[1], gg[0], ta, tb, Q4, RF_C6_NOASM, )
+            RF_C6_STEP(2, gg[0], gg[1], ta2, tb2, 1, RF_C6_NOASM, )
             wa_addr -= 4;
-            RF_C6_STEP(3, gg[1], gg[0], ta, tb, RF_TEXEL_OFFC(3), RF_C6_LOAD_WINDOW(wa_addr),
+            RF_C6_STEP(3, gg[1], gg[0], ta2, tb2, Q4 + 1, RF_C6_LOAD_WINDOW(wa_addr),
                        RF_C6_COMMA_W)
             ws8 = wn8;
             ta += 4;
             tb += 2;
+            ta2 += 4;
+            tb2 += 2;
         }
         {
             float wv[8];
             wv[0] = ws8[0]; wv[1] = ws8[1]; wv[2] = ws8[2]; wv[3] = ws8[3];
             wv[4] = ws8[4]; wv[5] = ws8[5]; wv[6] = ws8[6]; wv[7] = ws8[7];
-            RF_C6_STEP(0, gg[0], gg[1], ta, tb, RF_TEXEL_OFFC(0), RF_C6_NOASM, )
-            RF_C6_STEP(1, gg[1], gg[0], ta, tb, RF_TEXEL_OFFC(1), RF_C6_NOASM, )
+            RF_C6_STEP(0, gg[0], gg[1], ta, tb, 0, RF_C6_NOASM, )
+            RF_C6_STEP(1, gg[1], gg[0], ta, tb, Q4, RF_C6_NOASM, )
             // the columns past the end of this row carry no weight: fetch the next row's first two
-            RF_C6_STEP(2, gg[0], gg[1], ta_next, tb_next, 0, RF_C6_NOASM, )
-            RF_C6_STEP(3, gg[1], gg[0], ta_next, tb_next, Q4, RF_C6_LOAD_WINDOW(wa_next),
+            RF_C6_STEP(2, gg[0], gg[1], ta2_next, tb2_next, 0, RF_C6_NOASM, )
+            RF_C6_STEP(3, gg[1], gg[0], ta2_next, tb2_next, Q4, RF_C6_LOAD_WINDOW(wa_next),
                        RF_C6_COMMA_W)
             ws8 = wn8;
         }
         ta = ta_next;
         tb = tb_next;
+        ta2 = ta2_next;
+        tb2 = tb2_next;
         wa_addr = wa_next;
         ngroups = ngroups_next;
     }
@@ -1520,7 +1533,6 @@ __device__ __forceinline__ void jbf_tap_loop_rgb6(uint32_t lut_lane_addr,
 #undef RF_C6_COMMA_W
 #undef RF_C6_NOASM
 #undef RF_C6_STEP
-#undef RF_TEXEL_OFFC
 }
 #undef RF_LDS_READ_B64
 #undef RF_LDS_READ_B128
