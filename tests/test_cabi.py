@@ -163,6 +163,57 @@ def _vgprs(text):
     return regs
 
 
+def _lds_hazards(name, insts, flow):
+    """Walk the control-flow graph of one function with the queue of LDS reads in flight (destination
+    register sets, oldest first) and fail on any instruction that touches a register whose read has not
+    been waited for.  Returns the number of LDS reads seen."""
+    checked = 0
+    index_of = {a: i for i, a in enumerate(flow["addr"]) if a is not None}
+    seen = set()
+    work = [(0, ())]
+    while work:
+        i, pending = work.pop()
+        while i < len(insts):
+            key = (i, pending)
+            if key in seen:
+                break
+            seen.add(key)
+            op, args = insts[i]
+            busy = frozenset().union(*pending) if pending else frozenset()
+            if op.startswith("ds_"):     # every LDS operation takes a place in the in-order queue
+                reads = op.startswith("ds_read") or op.startswith("ds_load") or "_rtn" in op
+                dst = frozenset(_vgprs(args.split(",")[0])) if reads else frozenset()
+                # (its destination may be that of an older read: returns are in order)
+                srcs = args.split(",", 1)[1] if reads and "," in args else args
+                assert not (_vgprs(srcs) & busy), (name, op, args)
+                pending = pending + (dst,)
+                checked += 1 if reads else 0
+            elif op == "s_waitcnt":
+                m = re.search(r"lgkmcnt\((\d+)\)", args)
+                if m:
+                    keep = int(m.group(1))
+                    pending = pending[len(pending) - keep:] if 0 < keep < len(pending) else \
+                        (() if keep == 0 else pending)
+            elif op in ("s_endpgm", "s_setpc_b64"):
+                assert not pending, (name, op, "LDS reads still in flight at the end")
+                break
+            elif op.startswith("s_cbranch") or op == "s_branch":
+                target = flow["target"][i]
+                assert target is not None and flow["start"] + target in index_of, (name, op, args)
+                work.append((index_of[flow["start"] + target], pending))
+                if op == "s_branch":
+                    break
+            elif op != "s_barrier":
+                assert not (_vgprs(args) & busy), (name, op, args, sorted(busy)[:8])
+            # (the counter has 4 bits: with 15 operations outstanding the next one waits for the oldest;
+            #  a write at the head of the queue pins no register)
+            pending = pending[-15:]
+            while pending and not pending[0]:
+                pending = pending[1:]
+            i += 1
+    return checked
+
+
 def test_lds_reads_in_flight_are_not_touched_before_their_wait(disassembly):
     """The joint bilateral's asm tap loops issue LDS reads in one inline-asm statement and wait for
     them in a later one - the round-5 loop keeps four gathers in flight ACROSS a column step
@@ -179,51 +230,34 @@ def test_lds_reads_in_flight_are_not_touched_before_their_wait(disassembly):
         if "jbf_" not in name or "f32" in name:
             continue
         kernels += 1
-        flow = _FLOW[name]
-        index_of = {a: i for i, a in enumerate(flow["addr"]) if a is not None}
-        seen = set()
-        work = [(0, ())]                  # (instruction index, destination register sets, oldest first)
-        while work:
-            i, pending = work.pop()
-            while i < len(insts):
-                key = (i, pending)
-                if key in seen:
-                    break
-                seen.add(key)
-                op, args = insts[i]
-                busy = frozenset().union(*pending) if pending else frozenset()
-                if op.startswith("ds_"):     # every LDS operation takes a place in the in-order queue
-                    reads = op.startswith("ds_read") or op.startswith("ds_load") or "_rtn" in op
-                    dst = frozenset(_vgprs(args.split(",")[0])) if reads else frozenset()
-                    # (its destination may be that of an older read: returns are in order)
-                    srcs = args.split(",", 1)[1] if reads and "," in args else args
-                    assert not (_vgprs(srcs) & busy), (name, op, args)
-                    pending = pending + (dst,)
-                    checked += 1 if reads else 0
-                elif op == "s_waitcnt":
-                    m = re.search(r"lgkmcnt\((\d+)\)", args)
-                    if m:
-                        keep = int(m.group(1))
-                        pending = pending[len(pending) - keep:] if 0 < keep < len(pending) else \
-                            (() if keep == 0 else pending)
-                elif op in ("s_endpgm", "s_setpc_b64"):
-                    assert not pending, (name, op, "LDS reads still in flight at the end")
-                    break
-                elif op.startswith("s_cbranch") or op == "s_branch":
-                    target = flow["target"][i]
-                    assert target is not None and flow["start"] + target in index_of, (name, op, args)
-                    work.append((index_of[flow["start"] + target], pending))
-                    if op == "s_branch":
-                        break
-                elif op != "s_barrier":
-                    assert not (_vgprs(args) & busy), (name, op, args, sorted(busy)[:8])
-                # (the counter has 4 bits: with 15 operations outstanding the next one waits for the oldest;
-                #  a write at the head of the queue pins no register)
-                pending = pending[-15:]
-                while pending and not pending[0]:
-                    pending = pending[1:]
-                i += 1
+        checked += _lds_hazards(name, insts, _FLOW[name])
     assert kernels >= 8 and checked > 2000, (kernels, checked)
+
+
+def test_the_lds_hazard_check_follows_back_edges():
+    """The checker on hand-made code: a loop that leaves a gather in flight across its back edge is fine
+    as long as the loop's first instructions keep off the gather's register, and is caught when one of
+    them copies it - which a reading of the text from top to bottom would miss (nothing is in flight the
+    first time round)."""
+    def function(first):
+        insts = [first,
+                 ("ds_read_b32", "v1, v2"),
+                 ("s_waitcnt", "lgkmcnt(1)"),
+                 ("s_cmp_lg_u32", "s0, 0"),
+                 ("s_cbranch_scc1", "65531"),
+                 ("s_waitcnt", "lgkmcnt(0)"),
+                 ("v_mul_f32_e32", "v3, v1, v1"),
+                 ("s_endpgm", "")]
+        flow = {"start": 0x100, "addr": [0x100 + 4 * i for i in range(len(insts))],
+                "target": [None, None, None, None, 0, None, None, None]}
+        return insts, flow
+    assert _lds_hazards("ok", *function(("v_add_u32_e32", "v5, v5, v6"))) >= 1
+    with pytest.raises(AssertionError):
+        _lds_hazards("bad", *function(("v_mov_b32_e32", "v7, v1")))
+    with pytest.raises(AssertionError):      # ... and a read still in flight at the end
+        insts, flow = function(("v_add_u32_e32", "v5, v5, v6"))
+        insts[5] = ("s_nop", "0")
+        _lds_hazards("end", insts, flow)
 
 
 def test_dpp_reads_respect_the_valu_write_hazard(disassembly):
