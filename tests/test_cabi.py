@@ -129,29 +129,54 @@ def _sgprs(text):
     return regs
 
 
+def _smem_hazards(name, insts, flow):
+    """Walk the control-flow graph of one function with the set of SGPRs that scalar loads in flight will
+    write (scalar loads return out of order: only `lgkmcnt(0)` completes them) and fail on any instruction
+    that touches one of them.  Returns the number of scalar loads seen."""
+    checked = 0
+    index_of = {a: i for i, a in enumerate(flow["addr"]) if a is not None}
+    seen = set()
+    work = [(0, frozenset())]
+    while work:
+        i, pending = work.pop()
+        while i < len(insts):
+            if (i, pending) in seen:
+                break
+            seen.add((i, pending))
+            op, args = insts[i]
+            if op.startswith("s_load_dword"):
+                dst, _, rest = args.partition(",")
+                assert not (_sgprs(rest) & pending), (name, op, args)
+                pending = pending | frozenset(_sgprs(dst))
+                checked += 1
+            elif op == "s_waitcnt":
+                if "lgkmcnt(0)" in args:
+                    pending = frozenset()
+            elif op in ("s_endpgm", "s_setpc_b64"):
+                break
+            elif op.startswith("s_cbranch") or op == "s_branch":
+                target = flow["target"][i]
+                assert target is not None and flow["start"] + target in index_of, (name, op, args)
+                work.append((index_of[flow["start"] + target], pending))
+                if op == "s_branch":
+                    break
+            else:
+                assert not (_sgprs(args) & pending), (name, op, args, sorted(pending)[:4])
+            i += 1
+    return checked
+
+
 def test_inline_asm_scalar_loads_are_not_touched_before_their_wait(disassembly):
     """The CNN kernels issue s_load_dwordx16 / x2 in one inline-asm statement and wait for them in a
-    later one; the compiler does not know the loads are in flight, so nothing it places in between
-    may read or write their destination SGPRs (it could copy or spill stale values).  Checked on
-    the machine code of every kernel that streams weights this way."""
+    later one, the bilateral's tap loops their weight windows (s_load_dwordx8) and the next row's
+    half-width; the compiler does not know the loads are in flight, so nothing it places in between may
+    read or write their destination SGPRs (it could copy or spill stale values).  Checked on the
+    machine code of every kernel that streams this way, along every path of the control-flow graph."""
     checked = 0
     for name, insts in disassembly.items():
         if "cnn_reflectance" not in name and "jbf_tile64" not in name and "jbf_wide" not in name:
-            continue  # (round 5: the bilateral's grey tap loop streams its weight windows the same way)
-        pending = set()
-        for op, args in insts:
-            if op.startswith("s_load_dword"):
-                dst = args.split(",")[0]
-                rest = ",".join(args.split(",")[1:])
-                assert not (_sgprs(rest) & pending), (name, op, args)
-                pending |= _sgprs(dst)
-                checked += 1
-                continue
-            if op == "s_waitcnt" and "lgkmcnt(0)" in args:
-                pending = set()
-                continue
-            if pending:
-                assert not (_sgprs(args) & pending), (name, op, args, sorted(pending)[:4])
+            continue
+        checked += _smem_hazards(name, insts, _FLOW[name])
     assert checked > 20, "expected the weight-streaming scalar loads"
 
 
@@ -254,6 +279,20 @@ def test_the_lds_hazard_check_follows_back_edges():
     assert _lds_hazards("ok", *function(("v_add_u32_e32", "v5, v5, v6"))) >= 1
     with pytest.raises(AssertionError):
         _lds_hazards("bad", *function(("v_mov_b32_e32", "v7, v1")))
+    # the scalar-load walk on the same skeleton: a window requested at the loop's end, copied at its top
+    def scalar(first):
+        insts = [first,
+                 ("s_load_dwordx2", "s[4:5], s[0:1], 0x0"),
+                 ("s_cmp_lg_u32", "s8, 0"),
+                 ("s_cbranch_scc1", "65532"),
+                 ("s_waitcnt", "lgkmcnt(0)"),
+                 ("s_endpgm", "")]
+        flow = {"start": 0x100, "addr": [0x100 + 4 * i for i in range(len(insts))],
+                "target": [None, None, None, 0, None, None]}
+        return insts, flow
+    assert _smem_hazards("ok", *scalar(("s_add_i32", "s8, s8, -1"))) >= 1
+    with pytest.raises(AssertionError):
+        _smem_hazards("bad", *scalar(("s_mov_b32", "s9, s4")))
     with pytest.raises(AssertionError):      # ... and a read still in flight at the end
         insts, flow = function(("v_add_u32_e32", "v5, v5, v6"))
         insts[5] = ("s_nop", "0")
