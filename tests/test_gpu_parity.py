@@ -133,6 +133,29 @@ def test_jbf_wide_radius_tiles(env, ss, sc):
             assert np.array_equal(got[i], want.reshape(got[i].shape)), i
 
 
+def test_jbf_every_radius_of_the_tiled_kernels(env):
+    """Radius 1 .. 73 one by one (explicit diameter 2 r + 1): since round 5 a tap row starts at the even
+    column below its half-width and runs whole groups of four, so every radius walks its own pattern of
+    row phases and group counts - through the 64x64 tiles (radius <= 52, three row pitches), the row-band
+    kernel (53 .. 72) and, at 73, the untiled one.  Grey src and 1-channel buffers (the loop of the
+    CNN -> BF(CNN,CNN) chain) at every radius, a colour src at every third."""
+    from tests import synth
+    rf, co, torch = env
+    joint = synth.scene_u8(72, 88, seed=11)
+    grey = synth.reflectance_like_u8(72, 88, seed=12)
+    colour = synth.scene_u8(72, 88, seed=13)
+    g1 = np.ascontiguousarray(grey[:, :, 0])
+    g1_joint = g1.copy()          # (the same values in another buffer: passing src itself is OpenCV's
+    for radius in range(1, 74):   #  bilateralFilter route, test_jbf_same_buffer_takes_...)
+        d = 2 * radius + 1
+        srcs = [grey, g1] + ([colour] if radius % 3 == 0 else [])
+        for k, src in enumerate(srcs):
+            jnt = g1_joint if k == 1 else joint
+            got = rf.ximgproc.jointBilateralFilter(jnt, src, d, 20.0, 0.31 * radius + 0.7)
+            want = co.joint_bilateral_filter(jnt, src, d, 20.0, 0.31 * radius + 0.7)
+            assert np.array_equal(got, want), (radius, k)
+
+
 @pytest.mark.parametrize("d,ss,border", [(109, 3.0, 4), (121, 50.0, 2), (129, 7.5, 0), (137, 22.0, 1),
                                          (139, 22.0, 3), (145, 22.0, 4), (147, 9.0, 2)])
 def test_jbf_wide_diameter_with_any_sigma_and_border(env, d, ss, border):
