@@ -1098,120 +1098,80 @@ __device__ __forceinline__ void jbf_tap_loop_grey4_la2(uint32_t lut_lane_addr,
 #define RF_L2_READ_2 RF_L2_READ_0
 #define RF_L2_READ_1 ""
 #define RF_L2_READ_3 ""
-    // Step U of a group, first half: [texel pair]; SADs of column U + 2 interleaved with the weights
-    // of column U (GA = its gathered LUT values); src value of column U + 2.
-#define RF_L2_PART1A(U, GA, GB, TA, O0, O1)                                                                       \
-    float w0_, w1_, w2_, w3_;                                                                    \
-    uint32_t tj_;                                                                                \
-    asm volatile(RF_L2_READ(U)                                                                   \
-                 "v_and_b32 %[tj], %[mask], %[t2]\n\t"                                           \
-                 "v_sad_u8 %[a0], %[tj], %[jc0], 0\n\t"                                          \
-                 "v_mul_f32 %[w0], %[wv0], %[g0]\n\t"                                            \
-                 "v_sad_u8 %[a1], %[tj], %[jc1], 0\n\t"                                          \
-                 "v_mul_f32 %[w1], %[wv1], %[g1]\n\t"                                            \
-                 "v_sad_u8 %[a2], %[tj], %[jc2], 0\n\t"                                          \
-                 "v_mul_f32 %[w2], %[wv2], %[g2]\n\t"                                            \
-                 "v_sad_u8 %[a3], %[tj], %[jc3], 0\n\t"                                          \
-                 "v_mul_f32 %[w3], %[wv3], %[g3]\n\t"                                            \
-                 "v_cvt_f32_ubyte3 %[s2], %[t2]"                                                 \
-                 : RF_L2_TNOUT(U)[tj] "=&v"(tj_), [a0] "=&v"(GB[0]),                             \
-                   [a1] "=&v"(GB[1]), [a2] "=&v"(GB[2]), [a3] "=&v"(GB[3]), [w0] "=&v"(w0_),     \
-                   [w1] "=&v"(w1_), [w2] "=&v"(w2_), [w3] "=&v"(w3_), [s2] "=&v"(sv[((U) + 2) & 3]) \
-                 : [ta] "v"(TA), [o0] "n"(O0), [o1] "n"(O1), [mask] "v"(mask),                   \
-                   [t2] "v"(RF_L2_TQ((U) + 2)), [jc0] "v"(jc[0]),                                \
-                   [jc1] "v"(jc[1]), [jc2] "v"(jc[2]), [jc3] "v"(jc[3]), [wv0] "s"(wv[4 - (U)]), \
-                   [wv1] "s"(wv[5 - (U)]), [wv2] "s"(wv[6 - (U)]), [wv3] "s"(wv[7 - (U)]),       \
-                   [g0] "v"(GA[0]), [g1] "v"(GA[1]), [g2] "v"(GA[2]), [g3] "v"(GA[3]));
-#define RF_L2_PART1A_J1(U, GA, GB, TA, O0, O1)                                                                    \
-    float w0_, w1_, w2_, w3_;                                                                    \
-    uint32_t tj_;                                                                                \
-    asm volatile(RF_L2_READ(U)                                                                   \
-                 "v_and_b32 %[tj], %[mask], %[t2]\n\t"                                           \
-                 "v_sad_u32 %[a0], %[tj], %[jc0], %[la]\n\t"                                     \
-                 "v_mul_f32 %[w0], %[wv0], %[g0]\n\t"                                            \
-                 "v_sad_u32 %[a1], %[tj], %[jc1], %[la]\n\t"                                     \
-                 "v_mul_f32 %[w1], %[wv1], %[g1]\n\t"                                            \
-                 "v_sad_u32 %[a2], %[tj], %[jc2], %[la]\n\t"                                     \
-                 "v_mul_f32 %[w2], %[wv2], %[g2]\n\t"                                            \
-                 "v_sad_u32 %[a3], %[tj], %[jc3], %[la]\n\t"                                     \
-                 "v_mul_f32 %[w3], %[wv3], %[g3]\n\t"                                            \
-                 "v_cvt_f32_ubyte3 %[s2], %[t2]"                                                 \
-                 : RF_L2_TNOUT(U)[tj] "=&v"(tj_), [a0] "=&v"(GB[0]),                             \
-                   [a1] "=&v"(GB[1]), [a2] "=&v"(GB[2]), [a3] "=&v"(GB[3]), [w0] "=&v"(w0_),     \
-                   [w1] "=&v"(w1_), [w2] "=&v"(w2_), [w3] "=&v"(w3_), [s2] "=&v"(sv[((U) + 2) & 3]) \
-                 : [ta] "v"(TA), [o0] "n"(O0), [o1] "n"(O1), [mask] "v"(mask),                   \
-                   [la] "v"(lut_lane_addr), [t2] "v"(RF_L2_TQ((U) + 2)), [jc0] "v"(jc[0]),       \
-                   [jc1] "v"(jc[1]), [jc2] "v"(jc[2]), [jc3] "v"(jc[3]), [wv0] "s"(wv[4 - (U)]), \
-                   [wv1] "s"(wv[5 - (U)]), [wv2] "s"(wv[6 - (U)]), [wv3] "s"(wv[7 - (U)]),       \
-                   [g0] "v"(GA[0]), [g1] "v"(GA[1]), [g2] "v"(GA[2]), [g3] "v"(GA[3]));
-    // second half: gather addresses of column U + 2 interleaved with the weight sums of column U, the
-    // four gathers
-#define RF_L2_PART1B(GB)                                                                         \
-    asm volatile("v_lshl_add_u32 %[a0], %[a0], %[sh], %[la]\n\t"                                 \
-                 "v_add_f32 %[ws0], %[ws0], %[w0]\n\t"                                           \
-                 "v_lshl_add_u32 %[a1], %[a1], %[sh], %[la]\n\t"                                 \
-                 "v_add_f32 %[ws1], %[ws1], %[w1]\n\t"                                           \
-                 "v_lshl_add_u32 %[a2], %[a2], %[sh], %[la]\n\t"                                 \
-                 "v_add_f32 %[ws2], %[ws2], %[w2]\n\t"                                           \
-                 "v_lshl_add_u32 %[a3], %[a3], %[sh], %[la]\n\t"                                 \
-                 "v_add_f32 %[ws3], %[ws3], %[w3]\n\t"                                           \
-                 "ds_read_b32 %[a0], %[a0]\n\t"                                                  \
-                 "ds_read_b32 %[a1], %[a1]\n\t"                                                  \
-                 "ds_read_b32 %[a2], %[a2]\n\t"                                                  \
-                 "ds_read_b32 %[a3], %[a3]"                                                      \
-                 : [a0] "+v"(GB[0]), [a1] "+v"(GB[1]), [a2] "+v"(GB[2]), [a3] "+v"(GB[3]),       \
-                   [ws0] "+v"(wsum[0]), [ws1] "+v"(wsum[1]), [ws2] "+v"(wsum[2]),                \
-                   [ws3] "+v"(wsum[3])                                                           \
-                 : [sh] "n"(SHIFT), [la] "v"(lut_lane_addr), [w0] "v"(w0_), [w1] "v"(w1_),       \
-                   [w2] "v"(w2_), [w3] "v"(w3_));
-#define RF_L2_PART1B_J1(GB)                                                                      \
-    asm volatile("v_add_f32 %[ws0], %[ws0], %[w0]\n\t"                                           \
-                 "v_add_f32 %[ws1], %[ws1], %[w1]\n\t"                                           \
-                 "v_add_f32 %[ws2], %[ws2], %[w2]\n\t"                                           \
-                 "v_add_f32 %[ws3], %[ws3], %[w3]\n\t"                                           \
-                 "ds_read_b32 %[a0], %[a0]\n\t"                                                  \
-                 "ds_read_b32 %[a1], %[a1]\n\t"                                                  \
-                 "ds_read_b32 %[a2], %[a2]\n\t"                                                  \
-                 "ds_read_b32 %[a3], %[a3]"                                                      \
-                 : [a0] "+v"(GB[0]), [a1] "+v"(GB[1]), [a2] "+v"(GB[2]), [a3] "+v"(GB[3]),       \
-                   [ws0] "+v"(wsum[0]), [ws1] "+v"(wsum[1]), [ws2] "+v"(wsum[2]),                \
-                   [ws3] "+v"(wsum[3])                                                           \
-                 : [w0] "v"(w0_), [w1] "v"(w1_), [w2] "v"(w2_), [w3] "v"(w3_));
-    // accumulation of column U (its src value converted two steps ago); then everything but this
-    // step's four gathers has to be there: GN = the gathers of column U + 1, TN = the texel pair read in
-    // this step (any pair for odd steps)
-#define RF_L2_PART2(U, TN, GN, EXTRA_OPERANDS, WAITN)                                                   \
-    asm volatile("v_mul_f32 %[w0], %[w0], %[s]\n\t"                                              \
-                 "v_mul_f32 %[w1], %[w1], %[s]\n\t"                                              \
-                 "v_mul_f32 %[w2], %[w2], %[s]\n\t"                                              \
-                 "v_mul_f32 %[w3], %[w3], %[s]\n\t"                                              \
-                 "v_add_f32 %[s0], %[s0], %[w0]\n\t"                                             \
-                 "v_add_f32 %[s1], %[s1], %[w1]\n\t"                                             \
-                 "v_add_f32 %[s2], %[s2], %[w2]\n\t"                                             \
-                 "v_add_f32 %[s3], %[s3], %[w3]\n\t"                                             \
-                 "s_waitcnt lgkmcnt(" WAITN ")"                                                  \
-                 : [w0] "+v"(w0_), [w1] "+v"(w1_), [w2] "+v"(w2_), [w3] "+v"(w3_),               \
-                   [s0] "+v"(sum[0][0]), [s1] "+v"(sum[1][0]), [s2] "+v"(sum[2][0]),             \
-                   [s3] "+v"(sum[3][0]), "+v"(TN), "+v"(GN[0]), "+v"(GN[1]), "+v"(GN[2]),        \
-                   "+v"(GN[3]) EXTRA_OPERANDS()                                                  \
-                 : [s] "v"(sv[(U)]));
-    // (function-like so that the names travel through the macro levels unexpanded)
-#define RF_L2_NONE()
+    // Step U of a group, ONE statement (hipcc puts an s_nop at every boundary between asm statements:
+    // three per step cost 0.5 %): [texel pair]; SADs of column U + 2 interleaved with the weights of column
+    // U (GA = its gathered LUT values); src value of column U + 2; [MID: the group's full wait, step 3];
+    // gather addresses of column U + 2 interleaved with the weight sums of column U; the four gathers
+    // (clustered: an LDS instruction between VALU instructions costs their pairing); accumulation of
+    // column U (its src value converted two steps ago); the wait that leaves this step's four gathers in
+    // flight.  SADn / ADRn: the instruction that forms output n's table index and the one that turns it
+    // into an LDS address (J1: one v_sad_u32 does both).
+#define RF_L2_STEP_X(U, GA, GB, TA, O0, O1, MID, WAITTXT, SAD0, SAD1, SAD2, SAD3, ADR0, ADR1, ADR2, \
+                     ADR3)                                                                       \
+    {                                                                                            \
+        float w0_, w1_, w2_, w3_;                                                                \
+        uint32_t tj_;                                                                            \
+        asm volatile(RF_L2_READ(U)                                                               \
+                     "v_and_b32 %[tj], %[mask], %[t2]\n\t"                                       \
+                     SAD0 "v_mul_f32 %[w0], %[wv0], %[g0]\n\t"                                   \
+                     SAD1 "v_mul_f32 %[w1], %[wv1], %[g1]\n\t"                                   \
+                     SAD2 "v_mul_f32 %[w2], %[wv2], %[g2]\n\t"                                   \
+                     SAD3 "v_mul_f32 %[w3], %[wv3], %[g3]\n\t"                                   \
+                     "v_cvt_f32_ubyte3 %[s2], %[t2]\n\t"                                         \
+                     MID                                                                         \
+                     ADR0 "v_add_f32 %[ws0], %[ws0], %[w0]\n\t"                                  \
+                     ADR1 "v_add_f32 %[ws1], %[ws1], %[w1]\n\t"                                  \
+                     ADR2 "v_add_f32 %[ws2], %[ws2], %[w2]\n\t"                                  \
+                     ADR3 "v_add_f32 %[ws3], %[ws3], %[w3]\n\t"                                  \
+                     "ds_read_b32 %[a0], %[a0]\n\t"                                              \
+                     "ds_read_b32 %[a1], %[a1]\n\t"                                              \
+                     "ds_read_b32 %[a2], %[a2]\n\t"                                              \
+                     "ds_read_b32 %[a3], %[a3]\n\t"                                              \
+                     "v_mul_f32 %[w0], %[w0], %[s]\n\t"                                          \
+                     "v_mul_f32 %[w1], %[w1], %[s]\n\t"                                          \
+                     "v_mul_f32 %[w2], %[w2], %[s]\n\t"                                          \
+                     "v_mul_f32 %[w3], %[w3], %[s]\n\t"                                          \
+                     "v_add_f32 %[s0], %[s0], %[w0]\n\t"                                         \
+                     "v_add_f32 %[s1], %[s1], %[w1]\n\t"                                         \
+                     "v_add_f32 %[s2_], %[s2_], %[w2]\n\t"                                       \
+                     "v_add_f32 %[s3], %[s3], %[w3]\n\t"                                         \
+                     WAITTXT                                                                     \
+                     : RF_L2_TNOUT(U)[tj] "=&v"(tj_), [a0] "=&v"(GB[0]), [a1] "=&v"(GB[1]),      \
+                       [a2] "=&v"(GB[2]), [a3] "=&v"(GB[3]), [w0] "=&v"(w0_), [w1] "=&v"(w1_),   \
+                       [w2] "=&v"(w2_), [w3] "=&v"(w3_), [s2] "=&v"(sv[((U) + 2) & 3]),          \
+                       [ws0] "+v"(wsum[0]), [ws1] "+v"(wsum[1]), [ws2] "+v"(wsum[2]),            \
+                       [ws3] "+v"(wsum[3]), [s0] "+v"(sum[0][0]), [s1] "+v"(sum[1][0]),          \
+                       [s2_] "+v"(sum[2][0]), [s3] "+v"(sum[3][0])                               \
+                     : [ta] "v"(TA), [o0] "n"(O0), [o1] "n"(O1), [mask] "v"(mask),               \
+                       [t2] "v"(RF_L2_TQ((U) + 2)), [jc0] "v"(jc[0]), [jc1] "v"(jc[1]),          \
+                       [jc2] "v"(jc[2]), [jc3] "v"(jc[3]), [wv0] "s"(wv[4 - (U)]),               \
+                       [wv1] "s"(wv[5 - (U)]), [wv2] "s"(wv[6 - (U)]), [wv3] "s"(wv[7 - (U)]),   \
+                       [g0] "v"(GA[0]), [g1] "v"(GA[1]), [g2] "v"(GA[2]), [g3] "v"(GA[3]),       \
+                       [sh] "n"(SHIFT), [la] "v"(lut_lane_addr), [s] "v"(sv[(U)]));              \
+    }
+#define RF_L2_STEP(U, GA, GB, TA, O0, O1, MID, WAITTXT)                                           \
+    RF_L2_STEP_X(U, GA, GB, TA, O0, O1, MID, WAITTXT, "v_sad_u8 %[a0], %[tj], %[jc0], 0\n\t",      \
+                 "v_sad_u8 %[a1], %[tj], %[jc1], 0\n\t", "v_sad_u8 %[a2], %[tj], %[jc2], 0\n\t",  \
+                 "v_sad_u8 %[a3], %[tj], %[jc3], 0\n\t",                                         \
+                 "v_lshl_add_u32 %[a0], %[a0], %[sh], %[la]\n\t",                                \
+                 "v_lshl_add_u32 %[a1], %[a1], %[sh], %[la]\n\t",                                \
+                 "v_lshl_add_u32 %[a2], %[a2], %[sh], %[la]\n\t",                                \
+                 "v_lshl_add_u32 %[a3], %[a3], %[sh], %[la]\n\t")
+#define RF_L2_STEP_J1(U, GA, GB, TA, O0, O1, MID, WAITTXT)                                        \
+    RF_L2_STEP_X(U, GA, GB, TA, O0, O1, MID, WAITTXT, "v_sad_u32 %[a0], %[tj], %[jc0], %[la]\n\t", \
+                 "v_sad_u32 %[a1], %[tj], %[jc1], %[la]\n\t",                                    \
+                 "v_sad_u32 %[a2], %[tj], %[jc2], %[la]\n\t",                                    \
+                 "v_sad_u32 %[a3], %[tj], %[jc3], %[la]\n\t", "", "", "", "")
     // (The last step of a row waits like any other: four gathers stay in flight across the row loop's
     //  back edge, where the compiler writes code of its own - the next row's addresses.  That it moves
     //  none of the registers in flight there is checked on the machine code, along every path of the
     //  control-flow graph: tests/test_cabi.py.  A variant of this loop once got such a v_mov; a full wait
     //  at the row end, which this loop had until the check walked branches, costs 0.3 %.)
-    // ... which is waited for in the middle of step 3, where a full wait costs next to nothing: nothing
-    // is in flight there but the gathers of step 2, issued a whole step ago, and the window itself,
-    // requested three steps ago (step 3 reads no texel pair); step 3's own gathers follow the wait
-#define RF_L2_WAIT_WINDOW                                                                        \
-    asm volatile("s_waitcnt lgkmcnt(0)"                                                          \
-                 : "+v"(gg[0][0]), "+v"(gg[0][1]), "+v"(gg[0][2]), "+v"(gg[0][3]));
-    // the window changes hands after the group: the empty statement is ordered behind the wait above (both
-    // are volatile) and keeps the copy behind itself.  (Load and hand-over stand outside the two forms of
-    // a group so that no SGPR tuple meets itself at the join of a branch: the backend puts such a merge
-    // into VGPRs and then cannot give it back to an "s" operand.)
+    // the window changes hands after the group: the empty statement is ordered behind step 3 and its full
+    // wait (both are volatile) and keeps the copy behind itself.  (Load and hand-over are statements of
+    // their own, outside any branch: where an SGPR tuple written by an asm statement meets a value of
+    // another origin at a join, the backend merges them in VGPRs and cannot give the result back to an
+    // "s" operand.)
 #define RF_L2_HAND_OVER                                                                          \
     asm volatile("" : "+s"(wn8));                                                                \
     ws8 = wn8;
@@ -1221,35 +1181,18 @@ __device__ __forceinline__ void jbf_tap_loop_grey4_la2(uint32_t lut_lane_addr,
         const float *wp_ = swsym + (IDX);                                                        \
         asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=&s"(wn8) : "s"(wp_));                      \
     }
-    // one group of four steps; NB = base address of the texel pairs read ahead (this row's next group
-    // or the next row's first one), with the pair offsets P0A/P0B (columns 0, 1) and P2A/P2B (2, 3);
-    // WLOAD = the statement that loads the next weight window (after the window's last use in step
-    // 3, before that step's gathers)
-#define RF_L2_GROUP(P1A, P1B, NA, NB, PA, PB, WOPS, WAIT3)                                        \
+    // one group of four steps; NA / NB = address registers of the texel pairs read ahead (this row's next
+    // group or the next row's first one), PA / PB their ds_read2 offsets; the group's full wait - for the
+    // weight window requested before step 0 - sits in the middle of step 3, where nothing is in flight but
+    // the gathers of step 2, a whole step old (step 3 reads no texel pair)
+#define RF_L2_GROUP(STEP, NA, NB, PA, PB)                                                         \
     {                                                                                            \
-        {                                                                                        \
-            P1A(0, gg[0], gg[2], NA, PA, PB)                                               \
-            P1B(gg[2])                                                                           \
-            RF_L2_PART2(0, tp[0], gg[1], RF_L2_NONE, "4")                                                  \
-        }                                                                                        \
-        {                                                                                        \
-            P1A(1, gg[1], gg[3], NA, 0, 0)                                                   \
-            P1B(gg[3])                                                                           \
-            RF_L2_PART2(1, tp[0], gg[2], RF_L2_NONE, "4")                                                  \
-        }                                                                                        \
-        {                                                                                        \
-            P1A(2, gg[2], gg[0], NB, PA, PB)                                               \
-            P1B(gg[0])                                                                           \
-            RF_L2_PART2(2, tp[1], gg[3], RF_L2_NONE, "4")                                                  \
-        }                                                                                        \
-        {                                                                                        \
-            P1A(3, gg[3], gg[1], NB, 0, 0)                                                   \
-            RF_L2_WAIT_WINDOW                                                                    \
-            P1B(gg[1])                                                                           \
-            RF_L2_PART2(3, tp[1], gg[0], WOPS, WAIT3)                                            \
-        }                                                                                        \
+        STEP(0, gg[0], gg[2], NA, PA, PB, "", "s_waitcnt lgkmcnt(4)")                            \
+        STEP(1, gg[1], gg[3], NA, 0, 0, "", "s_waitcnt lgkmcnt(4)")                              \
+        STEP(2, gg[2], gg[0], NB, PA, PB, "", "s_waitcnt lgkmcnt(4)")                            \
+        STEP(3, gg[3], gg[1], NB, 0, 0, "s_waitcnt lgkmcnt(0)\n\t", "s_waitcnt lgkmcnt(4)")      \
     }
-#define RF_L2_ROW_LOOP(P1A, P1B)                                                                  \
+#define RF_L2_ROW_LOOP(STEP)                                                                      \
     for (int i = -radius; i <= radius; i++) {                                                     \
         uint32_t ta_next, tb_next, wa_next;                                                       \
         int ngroups_next;                                                                         \
@@ -1266,7 +1209,7 @@ __device__ __forceinline__ void jbf_tap_loop_grey4_la2(uint32_t lut_lane_addr,
             wv[4] = ws8[4]; wv[5] = ws8[5]; wv[6] = ws8[6]; wv[7] = ws8[7];                       \
             wa_addr -= 4;                                                                         \
             RF_L2_LOAD_WINDOW(wa_addr)                                                            \
-            RF_L2_GROUP(P1A, P1B, ta, tb, 1, Q4 + 1, RF_L2_NONE, "4")                             \
+            RF_L2_GROUP(STEP, ta, tb, 1, Q4 + 1)                                                 \
             RF_L2_HAND_OVER                                                                       \
             ta += 4;                                                                              \
             tb += 4;                                                                              \
@@ -1276,7 +1219,7 @@ __device__ __forceinline__ void jbf_tap_loop_grey4_la2(uint32_t lut_lane_addr,
             wv[0] = ws8[0]; wv[1] = ws8[1]; wv[2] = ws8[2]; wv[3] = ws8[3];                       \
             wv[4] = ws8[4]; wv[5] = ws8[5]; wv[6] = ws8[6]; wv[7] = ws8[7];                       \
             RF_L2_LOAD_WINDOW(wa_next)                                                            \
-            RF_L2_GROUP(P1A, P1B, ta_next, tb_next, 0, Q4, RF_L2_NONE, "4")                       \
+            RF_L2_GROUP(STEP, ta_next, tb_next, 0, Q4)                                           \
             RF_L2_HAND_OVER                                                                       \
         }                                                                                         \
         ta = ta_next;                                                                             \
@@ -1285,9 +1228,9 @@ __device__ __forceinline__ void jbf_tap_loop_grey4_la2(uint32_t lut_lane_addr,
         tb = tb_next;                                                                             \
     }
     if constexpr (J1) {
-        RF_L2_ROW_LOOP(RF_L2_PART1A_J1, RF_L2_PART1B_J1)
+        RF_L2_ROW_LOOP(RF_L2_STEP_J1)
     } else {
-        RF_L2_ROW_LOOP(RF_L2_PART1A, RF_L2_PART1B)
+        RF_L2_ROW_LOOP(RF_L2_STEP)
     }
     // the last steps' gathers (of a row that does not exist) are still in flight: nothing may re-use
     // their registers before they have landed
@@ -1298,14 +1241,10 @@ __device__ __forceinline__ void jbf_tap_loop_grey4_la2(uint32_t lut_lane_addr,
 #undef RF_L2_ROW_LOOP
 #undef RF_L2_GROUP
 #undef RF_L2_LOAD_WINDOW
-#undef RF_L2_WAIT_WINDOW
 #undef RF_L2_HAND_OVER
-#undef RF_L2_NONE
-#undef RF_L2_PART2
-#undef RF_L2_PART1B_J1
-#undef RF_L2_PART1B
-#undef RF_L2_PART1A_J1
-#undef RF_L2_PART1A
+#undef RF_L2_STEP_J1
+#undef RF_L2_STEP
+#undef RF_L2_STEP_X
 #undef RF_L2_READ
 #undef RF_L2_READ_0
 #undef RF_L2_READ_1
