@@ -1344,6 +1344,7 @@ __device__ __forceinline__ void jbf_tap_loop_rgb6(uint32_t lut_lane_addr,
     {                                                                                            \
         float w0_, w1_, w2_, w3_, s0_, s1_, s2_, m0_, m1_, m2_, m3_;                             \
         uint32_t tj_;                                                                            \
+        EXTRA_ASM /* (step 3: the next window's scalar load; the step ends in a full wait) */    \
         asm volatile("ds_read_b32 %[tn], %[ta] offset:%[off4]\n\t"                               \
                      "ds_read_u16 %[tnb], %[tb] offset:%[off2]\n\t"                              \
                      "v_and_b32 %[tj], %[mask], %[t1]\n\t"                                       \
@@ -1360,19 +1361,8 @@ __device__ __forceinline__ void jbf_tap_loop_rgb6(uint32_t lut_lane_addr,
                      "v_cvt_f32_ubyte0 %[s1], %[tb0]\n\t"                                        \
                      "v_add_f32 %[ws1], %[ws1], %[w1]\n\t"                                       \
                      "v_cvt_f32_ubyte1 %[s2], %[tb0]\n\t"                                        \
-                     "v_add_f32 %[ws2], %[ws2], %[w2]"                                           \
-                     : [tn] "=&v"(tq[((U) + 2) & 3]), [tnb] "=&v"(tqb[((U) + 2) & 3]),           \
-                       [tj] "=&v"(tj_), [a0] "=&v"(GB[0]), [a1] "=&v"(GB[1]), [a2] "=&v"(GB[2]), \
-                       [a3] "=&v"(GB[3]), [w0] "=&v"(w0_), [w1] "=&v"(w1_), [w2] "=&v"(w2_),     \
-                       [w3] "=&v"(w3_), [s0] "=&v"(s0_), [s1] "=&v"(s1_), [s2] "=&v"(s2_),       \
-                       [ws0] "+v"(wsum[0]), [ws1] "+v"(wsum[1]), [ws2] "+v"(wsum[2])             \
-                     : [ta] "v"(TA), [tb] "v"(TB), [off4] "n"((OFFT) * 4), [off2] "n"((OFFT) * 2), \
-                       [mask] "v"(mask), [t1] "v"(tq[((U) + 1) & 3]), [t0] "v"(tq[(U)]),         \
-                       [tb0] "v"(tqb[(U)]), [jc0] "v"(jc[0]), [jc1] "v"(jc[1]), [jc2] "v"(jc[2]), \
-                       [jc3] "v"(jc[3]), [wv0] "s"(wv[4 - (U)]), [wv1] "s"(wv[5 - (U)]),         \
-                       [wv2] "s"(wv[6 - (U)]), [wv3] "s"(wv[7 - (U)]), [g0] "v"(GA[0]),          \
-                       [g1] "v"(GA[1]), [g2] "v"(GA[2]), [g3] "v"(GA[3]));                       \
-        asm volatile("v_lshl_add_u32 %[a0], %[a0], %[sh], %[la]\n\t"                             \
+                     "v_add_f32 %[ws2], %[ws2], %[w2]\n\t"                                       \
+                     "v_lshl_add_u32 %[a0], %[a0], %[sh], %[la]\n\t"                             \
                      "v_add_f32 %[ws3], %[ws3], %[w3]\n\t"                                       \
                      "v_lshl_add_u32 %[a1], %[a1], %[sh], %[la]\n\t"                             \
                      "v_mul_f32 %[m0], %[w0], %[s0]\n\t"                                         \
@@ -1383,13 +1373,8 @@ __device__ __forceinline__ void jbf_tap_loop_rgb6(uint32_t lut_lane_addr,
                      "ds_read_b32 %[a0], %[a0]\n\t"                                              \
                      "ds_read_b32 %[a1], %[a1]\n\t"                                              \
                      "ds_read_b32 %[a2], %[a2]\n\t"                                              \
-                     "ds_read_b32 %[a3], %[a3]"                                                  \
-                     : [a0] "+v"(GB[0]), [a1] "+v"(GB[1]), [a2] "+v"(GB[2]), [a3] "+v"(GB[3]),   \
-                       [ws3] "+v"(wsum[3]), [m0] "=&v"(m0_), [m1] "=&v"(m1_), [m2] "=&v"(m2_)    \
-                     : [sh] "n"(SHIFT), [la] "v"(lut_lane_addr), [w0] "v"(w0_), [w1] "v"(w1_),   \
-                       [w2] "v"(w2_), [w3] "v"(w3_), [s0] "v"(s0_));                             \
-        EXTRA_ASM                                                                                \
-        asm volatile("v_mul_f32 %[m3], %[w3], %[s0]\n\t"                                         \
+                     "ds_read_b32 %[a3], %[a3]\n\t"                                              \
+                     "v_mul_f32 %[m3], %[w3], %[s0]\n\t"                                         \
                      "v_add_f32 %[c00], %[c00], %[m0]\n\t"                                       \
                      "v_add_f32 %[c10], %[c10], %[m1]\n\t"                                       \
                      "v_add_f32 %[c20], %[c20], %[m2]\n\t"                                       \
@@ -1411,15 +1396,25 @@ __device__ __forceinline__ void jbf_tap_loop_rgb6(uint32_t lut_lane_addr,
                      "v_add_f32 %[c22], %[c22], %[m2]\n\t"                                       \
                      "v_add_f32 %[c32], %[c32], %[m3]\n\t"                                       \
                      "s_waitcnt lgkmcnt(0)"                                                      \
-                     : [m0] "+v"(m0_), [m1] "+v"(m1_), [m2] "+v"(m2_), [m3] "=&v"(m3_),          \
+                     : [tn] "=&v"(tq[((U) + 2) & 3]), [tnb] "=&v"(tqb[((U) + 2) & 3]),           \
+                       [tj] "=&v"(tj_), [a0] "=&v"(GB[0]), [a1] "=&v"(GB[1]), [a2] "=&v"(GB[2]), \
+                       [a3] "=&v"(GB[3]), [w0] "=&v"(w0_), [w1] "=&v"(w1_), [w2] "=&v"(w2_),     \
+                       [w3] "=&v"(w3_), [s0] "=&v"(s0_), [s1] "=&v"(s1_), [s2] "=&v"(s2_),       \
+                       [m0] "=&v"(m0_), [m1] "=&v"(m1_), [m2] "=&v"(m2_), [m3] "=&v"(m3_),       \
+                       [ws0] "+v"(wsum[0]), [ws1] "+v"(wsum[1]), [ws2] "+v"(wsum[2]),            \
+                       [ws3] "+v"(wsum[3]),                                                      \
                        [c00] "+v"(sum[0][0]), [c10] "+v"(sum[1][0]), [c20] "+v"(sum[2][0]),      \
                        [c30] "+v"(sum[3][0]), [c01] "+v"(sum[0][1]), [c11] "+v"(sum[1][1]),      \
                        [c21] "+v"(sum[2][1]), [c31] "+v"(sum[3][1]), [c02] "+v"(sum[0][2]),      \
-                       [c12] "+v"(sum[1][2]), [c22] "+v"(sum[2][2]), [c32] "+v"(sum[3][2]),      \
-                       "+v"(tq[((U) + 2) & 3]), "+v"(tqb[((U) + 2) & 3]), "+v"(GB[0]),           \
-                       "+v"(GB[1]), "+v"(GB[2]), "+v"(GB[3]) EXTRA_OPERANDS                      \
-                     : [w0] "v"(w0_), [w1] "v"(w1_), [w2] "v"(w2_), [w3] "v"(w3_),               \
-                       [s0] "v"(s0_), [s1] "v"(s1_), [s2] "v"(s2_));                             \
+                       [c12] "+v"(sum[1][2]), [c22] "+v"(sum[2][2]), [c32] "+v"(sum[3][2])       \
+                       EXTRA_OPERANDS                                                            \
+                     : [ta] "v"(TA), [tb] "v"(TB), [off4] "n"((OFFT) * 4), [off2] "n"((OFFT) * 2), \
+                       [mask] "v"(mask), [t1] "v"(tq[((U) + 1) & 3]), [t0] "v"(tq[(U)]),         \
+                       [tb0] "v"(tqb[(U)]), [jc0] "v"(jc[0]), [jc1] "v"(jc[1]), [jc2] "v"(jc[2]), \
+                       [jc3] "v"(jc[3]), [wv0] "s"(wv[4 - (U)]), [wv1] "s"(wv[5 - (U)]),         \
+                       [wv2] "s"(wv[6 - (U)]), [wv3] "s"(wv[7 - (U)]), [g0] "v"(GA[0]),          \
+                       [g1] "v"(GA[1]), [g2] "v"(GA[2]), [g3] "v"(GA[3]), [sh] "n"(SHIFT),       \
+                       [la] "v"(lut_lane_addr));                                                 \
     }
 #define RF_C6_NOASM
 #define RF_C6_COMMA_W , "+s"(wn8)
