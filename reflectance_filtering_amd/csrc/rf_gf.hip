@@ -481,12 +481,17 @@ __global__ __launch_bounds__(stage1_threads(SCN)) void gf_stage1_kernel(
         {
             // lanes 0 .. kAWaves-2-wave add the wave total (lane 63's prefix) to the entries of the
             // waves to the right
+            // (all the totals first, then ONE masked region with the atomics: per quantity hipcc
+            //  opens and closes the mask around each)
             const int dstw = wave + 1 + lane;
+            uint32_t tot[NQ];
 #pragma unroll
-            for (int q = 0; q < NQ; q++) {
-                const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl[q], 63);
-                if (dstw < kAWaves)
-                    atomicAdd(&wave_acc[q][dstw], tot);
+            for (int q = 0; q < NQ; q++)
+                tot[q] = (uint32_t)__builtin_amdgcn_readlane((int)incl[q], 63);
+            if (dstw < kAWaves) {
+#pragma unroll
+                for (int q = 0; q < NQ; q++)
+                    atomicAdd(&wave_acc[q][dstw], tot[q]);
             }
         }
         RF_S1_STAMP(1);
