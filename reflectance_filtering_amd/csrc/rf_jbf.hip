@@ -1612,8 +1612,11 @@ __global__ __launch_bounds__(1024) void jbf_tile64_kernel(
     constexpr int Q4 = TLW / 4;
     extern __shared__ __align__(16) unsigned char smem[];
     volatile int *flag_word = reinterpret_cast<volatile int *>(smem);
+    // (the asm tap loops take their weights through scalar loads: the LDS copy of the weight table is
+    //  staged only for the compiler-scheduled loop and the round-4 loop, the test / A-B aids)
+    const bool need_sw = (flags & (kJbfCompilerLoop | kJbfLookahead1)) != 0;
     float *swl = reinterpret_cast<float *>(smem + 16);
-    const int sw_bytes = ((radius + 1) * sw_len * 4 + 15) & ~15;
+    const int sw_bytes = need_sw ? ((radius + 1) * sw_len * 4 + 15) & ~15 : 0;
     unsigned char *tile_raw = smem + 16 + sw_bytes;
     if (threadIdx.x == 0)
         *flag_word = 3;
@@ -1631,8 +1634,9 @@ __global__ __launch_bounds__(1024) void jbf_tile64_kernel(
     const int ty = tid / QW;
 
     // ---- weight table, grey LUT (optimistic), grey-packed tile ----
-    for (int i = tid; i < (radius + 1) * sw_len; i += NT)
-        swl[i] = swsym[i];
+    if (need_sw)
+        for (int i = tid; i < (radius + 1) * sw_len; i += NT)
+            swl[i] = swsym[i];
     float *lut_g = reinterpret_cast<float *>(smem + kT64Lds - nz * GREP * 4);
     for (int i = tid; i < nz * GREP; i += NT)
         lut_g[i] = lut[i / GREP];
@@ -2035,11 +2039,13 @@ int lds_oob_reads_zero(int dev, bool *ok)
 // LDS needed by jbf_tile64_kernel for grey / colour tiles with the given LUT replication.
 // Rows per colour pass that fit (64 = one pass with 6-byte texels; 32, 16, 8 = passes with
 // 8-byte texels), or 0.
-int tile64_fits(const JbfTables &t, int nz, int grep, int crep, int scn, int tlw, int th = 64)
+int tile64_fits(const JbfTables &t, int nz, int grep, int crep, int scn, int tlw, int th, int flags)
 {
     if (2 * t.r4 + 4 * (1024 / th) + 8 > tlw)
         return 0;
-    const size_t sw_bytes = 16 + (((size_t)(t.radius + 1) * t.sw_len * 4 + 15) & ~(size_t)15);
+    const bool need_sw = (flags & (kJbfCompilerLoop | kJbfLookahead1)) != 0;  // as in the kernel
+    const size_t sw_bytes =
+        16 + (need_sw ? ((size_t)(t.radius + 1) * t.sw_len * 4 + 15) & ~(size_t)15 : 0);
     const size_t grey = sw_bytes + (size_t)tlw * (th + 2 * t.radius) * 4 + (size_t)nz * grep * 4;
     if (grey > (size_t)kT64Lds)
         return 0;
@@ -2097,13 +2103,13 @@ int launch_tile64_rows(const JbfTables &t, int nz, int crows, const uint8_t *joi
     // ---- right strip (single-channel sources)
     int sx = 0;
     if (SCN == 1 && !only64 && (w & 63) > 0 && (w & 63) <= 32 &&
-        tile64_fits(t, nz, GREP, CREP, SCN, 136, 128) > 0 && ceil_div(h, 128) < ceil_div(h, 64))
+        tile64_fits(t, nz, GREP, CREP, SCN, 136, 128, flags) > 0 && ceil_div(h, 128) < ceil_div(h, 64))
         sx = w & 63;
     const int cols_main = w - sx;
     // ---- bottom strips
     const int rem = h & 63;
-    const bool ok32 = tile64_fits(t, nz, GREP, CREP, SCN, 208, 32) > 0;
-    const bool ok16 = SCN == 1 && tile64_fits(t, nz, GREP, CREP, SCN, 336, 16) > 0;
+    const bool ok32 = tile64_fits(t, nz, GREP, CREP, SCN, 208, 32, flags) > 0;
+    const bool ok16 = SCN == 1 && tile64_fits(t, nz, GREP, CREP, SCN, 336, 16, flags) > 0;
     int s32 = 0, s16 = 0;  // rows given to each strip
     if (rem > 0 && rem <= 16 && ok16)
         s16 = rem;
@@ -2514,8 +2520,9 @@ extern "C" int rf_jbf_u8(const uint8_t *joint, const uint8_t *src, uint8_t *dst,
             // row pitch 144 serves radius <= 36, 176 radius <= 52 (colour tiles of the wide
             // pitch run in 16- or 8-row passes)
 #define RF_T64(G_, C_, W_)                                                                        \
-    if (!done && tile64_fits(t, nz, G_, C_, src_cn, W_) > 0) {                                    \
-        const int crows_ = tile64_fits(t, nz, G_, C_, src_cn, W_);                                \
+    if (!done && (min_rows < 64 || C_ >= 8) &&                                                    \
+        tile64_fits(t, nz, G_, C_, src_cn, W_, 64, flags) >= min_rows) {                          \
+        const int crows_ = tile64_fits(t, nz, G_, C_, src_cn, W_, 64, flags);                     \
         if (W_ == 144)                                                                            \
             rc = src_cn == 3 ? launch_tile64_rows<3, G_, C_>(t, nz, crows_, joint, src, dst, n,   \
                                                              h, w, jcn_kernel, border, flags,     \
@@ -2532,14 +2539,22 @@ extern "C" int rf_jbf_u8(const uint8_t *joint, const uint8_t *src, uint8_t *dst,
             return rc;                                                                            \
         done = true;                                                                              \
     }
-            RF_T64(32, 32, 144)
-            RF_T64(32, 16, 144)
-            RF_T64(16, 8, 144)
-            RF_T64(8, 4, 144)
-            RF_T64(32, 16, 176)
-            RF_T64(32, 4, 176)
-            RF_T64(16, 8, 176)
-            RF_T64(8, 4, 176)
+            // A colour src first looks for a shape whose colour tile fits in ONE pass over the 64 rows,
+            // on all 1024 lanes, even with fewer LUT replicas - down to 8 - (the reference's c15 s28,
+            // README.md:64, at pitch 176: 8 replicas, +3.5 % over two 32-row passes on half the lanes
+            // with 16), then for one that needs passes.
+            for (int min_rows = src_cn == 3 ? 64 : 1; min_rows >= 1 && !done;
+                 min_rows = min_rows == 64 ? 1 : 0) {
+                RF_T64(32, 32, 144)
+                RF_T64(32, 16, 144)
+                RF_T64(16, 8, 144)
+                RF_T64(8, 4, 144)
+                RF_T64(32, 16, 176)
+                RF_T64(32, 8, 176)
+                RF_T64(32, 4, 176)
+                RF_T64(16, 8, 176)
+                RF_T64(8, 4, 176)
+            }
 #undef RF_T64
             // radius 53..72: row-band passes of the grey loop (the most rows per pass first, then the
             // most LUT replicas: half the rows is half the lanes, fewer replicas a few bank conflicts)
