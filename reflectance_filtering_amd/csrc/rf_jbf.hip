@@ -1578,16 +1578,18 @@ __global__ __launch_bounds__(16 * TH) void jbf_tiled2_kernel(
 //   * grey src (single-channel src, or every src texel of the tile has B = G = R -- the case of
 //     the reference's `-r.png`): the tile is staged as 4-byte texels {B,G,R joint, grey src}.
 //     That halves the tile (130 rows x 144 x 4 B = 73 KB), which is what lets a 64-row tile, a
-//     32x replicated (conflict-free) LUT and the weight table share 160 KB of LDS, i.e. what
-//     buys 4 waves per SIMD.  All 1024 threads run the single-channel loop.
-//   * colour src: the tile is processed as two 32-row halves with 8-byte texels (98 x 144 x 8 B)
-//     and a 16x LUT; threads 0..511 run the 3-channel loop for each half, the others help stage.
+//     32x replicated (conflict-free) LUT and - for the test aids - the weight table share 160 KB
+//     of LDS, i.e. what buys 4 waves per SIMD.  All 1024 threads run the single-channel loop.
+//   * colour src: a second plane of 2-byte texels {G src, R src} beside the grey-packed one (6 bytes
+//     per texel), one pass on all 1024 threads where that fits with at least 8 LUT replicas (radius
+//     33: 32 replicas; the reference's c15 s28 at pitch 176: 8); otherwise passes of 32 / 16 / 8
+//     rows of the same two planes, run by threads 0 .. 16 * rows - 1 while all threads stage.
 // The colour LUT sits at the END of the workgroup's 163,840-byte LDS allocation and holds only
 // the entries before its zero tail: an index past the table addresses LDS beyond the
 // allocation, where ds_read returns 0 -- exactly the LUT value there -- so the per-tap clamp
 // disappears.  rf_jbf_u8 verifies that behaviour once per device with a probe kernel and uses
 // the clamping kernel above if it ever does not hold.
-// LDS: [flag][sw table][tile ...                   free ...][LUT nz*REP f32] = 163,840 B
+// LDS: [flag][sw table: test aids only][tile ...     free ...][LUT nz*REP f32] = 163,840 B
 // ------------------------------------------------------------------------------------------
 constexpr int kT64Lds = 163840;
 
