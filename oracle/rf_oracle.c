@@ -456,6 +456,10 @@ static void rfo_box_mean(const float *src, float *dst, int h, int w, int r)
  *   c[8] rows that pass the order-free sufficient test: every non-zero value of the row is a
  *        multiple of 2^e (e = its float exponent - 23) and ks * max|v| < 2^(e_min + 53)
  *   c[9] planes            c[10] planes with no rounded operation at all
+ *   c[11] blocks of 64 rows  c[12] blocks that pass the JOINT test the GPU's stage 1 evaluates per
+ *        (64-row block, plane): exponent fields of the largest and of the smallest non-zero
+ *        magnitude of the whole block, Emax - max(Emin, 1) <= 29 - ceil(log2 ks)
+ *        (reflectance_filtering_amd/csrc/rf_gf.hip, "exact rows")
  */
 static unsigned long long g_rfo_census[16];
 static int g_rfo_census_on;
@@ -483,11 +487,35 @@ static void rfo_box_mean_census(const float *src, float *dst, int h, int w, int 
     double *rows = (double *)malloc(sizeof(double) * (size_t)h * w);
     int ew = w + ks - 1;
     float *ext = (float *)malloc(sizeof(float) * ew);
+    int lim = 29;
+    while ((1 << (29 - lim)) < ks)
+        lim--;
+    unsigned bmax = 0, bmin = 0xffffffffu;
     for (int y = 0; y < h; y++) {
         const float *S0 = src + (size_t)y * w;
         double *D = rows + (size_t)y * w;
         int emin = 10000;
         float vmax = 0.f;
+        for (int x = 0; x < w; x++) {
+            unsigned u;
+            memcpy(&u, &S0[x], 4);
+            u &= 0x7fffffffu;
+            if (u > bmax)
+                bmax = u;
+            if (u != 0 && u < bmin)
+                bmin = u;
+        }
+        if ((y & 63) == 63 || y == h - 1) {
+            int e1 = (int)(bmax >> 23), e0 = (int)(bmin >> 23);
+            if (e0 < 1)
+                e0 = 1;
+            if (e1 < 1)
+                e1 = 1;
+            c[11]++;
+            c[12] += (bmax == 0 || e1 - e0 <= lim);
+            bmax = 0;
+            bmin = 0xffffffffu;
+        }
         for (int x = 0; x < ew; x++) {
             float v = S0[rfo_border_interpolate(x - r, w, RFO_BORDER_REFLECT)];
             ext[x] = v;

@@ -22,7 +22,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 NAMES = ("rows", "rows_rounded", "row_ops", "row_ops_rounded", "cols", "cols_rounded", "col_ops",
-         "col_ops_rounded", "rows_pass_order_free_test", "planes", "planes_exact")
+         "col_ops_rounded", "rows_pass_order_free_test", "planes", "planes_exact", "blocks64",
+         "blocks64_pass_joint_test")
 
 
 def census_run(L, guide, src, radius, eps, passes):
@@ -77,19 +78,22 @@ def main():
              "operations rounded - its sums are then order-free." % (h, w, args.radius, args.eps,
                                                                     args.passes, w, h), ""]
     lines.append("| case | pass | planes | planes fully exact | rows exact | rounded row ops | "
-                 "columns exact | rounded column ops | rows passing the order-free test |")
-    lines.append("|---|---|---|---|---|---|---|---|---|")
+                 "columns exact | rounded column ops | rows passing the order-free test | "
+                 "64-row blocks passing the joint test (per plane) |")
+    lines.append("|---|---|---|---|---|---|---|---|---|---|")
     for name, g, s in cases:
         t0 = time.time()
         res = census_run(L, g, s, args.radius, args.eps, args.passes)
         for k, c in enumerate(res):
-            lines.append("| %s | %d | %d | %d | %.4f %% | %.3e of %.3e | %.4f %% | %.3e of %.3e | %.4f %% |" % (
+            lines.append("| %s | %d | %d | %d | %.4f %% | %.3e of %.3e | %.4f %% | %.3e of %.3e | %.4f %% | %d of %d (%.2f %%) |" % (
                 name, k + 1, c["planes"], c["planes_exact"],
                 100.0 * (c["rows"] - c["rows_rounded"]) / max(1, c["rows"]),
                 c["row_ops_rounded"], c["row_ops"],
                 100.0 * (c["cols"] - c["cols_rounded"]) / max(1, c["cols"]),
                 c["col_ops_rounded"], c["col_ops"],
-                100.0 * c["rows_pass_order_free_test"] / max(1, c["rows"])))
+                100.0 * c["rows_pass_order_free_test"] / max(1, c["rows"]),
+                c["blocks64_pass_joint_test"], c["blocks64"],
+                100.0 * c["blocks64_pass_joint_test"] / max(1, c["blocks64"])))
         sys.stderr.write("%s: %.1f s\n" % (name, time.time() - t0))
     txt = "\n".join(lines) + "\n"
     sys.stdout.write(txt)
