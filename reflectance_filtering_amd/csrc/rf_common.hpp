@@ -92,6 +92,7 @@ enum DebugOption {
     kDbgGfS1Cap,           // guided filter: stage-1 workgroups per CU (dynamic-LDS pad), 0 = whatever fits
     kDbgGfS1MinWgs,        // guided filter: workgroups a stage-1 launch should at least have (0 = chosen by the library)
     kDbgJbfLookahead1,     // joint bilateral: grey asm loop with the gathers one column step ahead (round-4 form)
+    kDbgGfS1LegacyStrips,  // guided filter: stage-1 strips with a halo of exactly r columns on either side (rounds 1-5)
     kDbgCount
 };
 int debug_get(int id);

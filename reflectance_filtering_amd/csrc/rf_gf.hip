@@ -310,8 +310,11 @@ template <int SCN, int SPX, int MODE>
 __global__ __launch_bounds__(stage1_threads(SCN)) void gf_stage1_kernel(
     const uint8_t *__restrict__ guide, const uint8_t *__restrict__ src, float *__restrict__ ab,
     int h, int w, int radius, float eps_f, int eps_small, int seg_rows,
-    const int *__restrict__ colour, float *__restrict__ gs, int ab_groups)
+    const int *__restrict__ colour, float *__restrict__ gs, int ab_groups, int hl, int out_w)
 {
+    // hl, out_w: the strip's geometry - its kACW columns are image columns xs - hl .. xs - hl + kACW - 1
+    // (xs = strip index x out_w), of which columns hl .. hl + out_w - 1 are its outputs; hl >= radius
+    // and kACW - hl - out_w >= radius (rf_gf_u8 picks them, see gf_strip_geometry)
     // ab_groups: plane groups (src channels) an image has in ab - SPX, or 3 when a grey 3-channel
     // image is read from its one-byte-per-pixel intermediate (SPX = 1, see rf_gf_u8)
     if (wrong_variant<SCN>(colour, blockIdx.z))
@@ -326,7 +329,6 @@ __global__ __launch_bounds__(stage1_threads(SCN)) void gf_stage1_kernel(
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int out_w = kACW - 2 * radius;
     const int xs = blockIdx.x * out_w;
     const int ys = blockIdx.y * seg_rows;
     const int ye = min(ys + seg_rows, h);
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(stage1_threads(SCN)) void gf_stage1_kernel(
     uint32_t gx3[kACols], gxs[kACols];
 #pragma unroll
     for (int k = 0; k < kACols; k++) {
-        const int gx = border_interpolate(xs - radius + tid * kACols + k, w, RF_BORDER_REFLECT);
+        const int gx = border_interpolate(xs - hl + tid * kACols + k, w, RF_BORDER_REFLECT);
         gx3[k] = (uint32_t)gx * 3u;
         gxs[k] = (uint32_t)gx * (uint32_t)SPX;
     }
@@ -406,12 +408,20 @@ __global__ __launch_bounds__(stage1_threads(SCN)) void gf_stage1_kernel(
             wave_acc[q][tid] = 0;
     __syncthreads();
 
-    bool col_ok[kACols], all_ok = true;
+    // Per-pixel phase (window means -> algebra -> alpha/beta): the strip's columns are dealt to the
+    // threads one by one, thread t taking columns pc[k] = t' + kAThreads * k (the prefix sums are in LDS:
+    // any thread can serve any column).  A wave then stores 64 consecutive pixels (1 KB) per
+    // instruction, its 16-lane rows are 16 consecutive columns, and with a halo of a whole wave on
+    // either side (hl = 64, out_w = kACW - 128: 3840 = 6 x 640, 1920 = 3 x 640) two of the strip's
+    // twelve wave-iterations have no output column at all and are skipped - which waves those are
+    // alternates with the workgroup's parity (t' = t rotated by two waves), so that the four SIMDs
+    // of a CU see the same load.
+    const int tidp = (tid + ((blockIdx.x + blockIdx.y + blockIdx.z) & 1) * (kAThreads / 2)) & (kAThreads - 1);
+    bool col_ok[kACols];
 #pragma unroll
     for (int k = 0; k < kACols; k++) {
-        const int c = tid * kACols + k;
-        col_ok[k] = !(c < radius || c >= kACW - radius || xs - radius + c >= w);
-        all_ok = all_ok && col_ok[k];
+        const int c = tidp + kAThreads * k;
+        col_ok[k] = c >= hl && c < hl + out_w && xs - hl + c < w;
     }
 #ifdef RF_GF_S1_STAMP
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -425,25 +435,14 @@ __global__ __launch_bounds__(stage1_threads(SCN)) void gf_stage1_kernel(
         //  and store instruction of a wave touch 54 cache lines and cost more than they saved)
         float gsr[kACols][kGsFloats];
         if (MODE == kS1Reuse) {
-            const float *rec = gsimg + (size_t)y * kGsFloats * w + (xs - radius + tid * kACols);
-            if (all_ok) {
+            const float *rec = gsimg + (size_t)y * kGsFloats * w + (xs - hl + tidp);
 #pragma unroll
-                for (int e = 0; e < kGsFloats; e++) {
-                    float t[kACols];
-                    __builtin_memcpy(t, rec + (size_t)e * w, sizeof(t));
+            for (int k = 0; k < kACols; k++) {
+                if (!col_ok[k])
+                    continue;
 #pragma unroll
-                    for (int k = 0; k < kACols; k++)
-                        gsr[k][e] = t[k];
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < kACols; k++) {
-                    if (!col_ok[k])
-                        continue;
-#pragma unroll
-                    for (int e = 0; e < kGsFloats; e++)
-                        gsr[k][e] = rec[(size_t)e * w + k];
-                }
+                for (int e = 0; e < kGsFloats; e++)
+                    gsr[k][e] = rec[(size_t)e * w + kAThreads * k];
             }
         }
         add_row(y + radius, RowIn{});
@@ -514,9 +513,9 @@ __global__ __launch_bounds__(stage1_threads(SCN)) void gf_stage1_kernel(
         RF_S1_STAMP(4);
 #pragma unroll
         for (int k = 0; k < kACols; k++) {
-            const int c = tid * kACols + k;
-            const int x = xs - radius + c;
-            if (c < radius || c >= kACW - radius || x >= w)
+            const int c = tidp + kAThreads * k;
+            const int x = xs - hl + c;
+            if (!col_ok[k])
                 continue;
             float m[NQ];
 #pragma unroll
@@ -1183,9 +1182,33 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
         chunk &= ~15;
     const float eps_f = (float)eps;
     const int eps_small = eps < 1e-2;
-    // stage-1 strips: stage1_threads x stage1_cols columns, 2r of them halo
-    const int strips3 = ceil_div(w, stage1_threads(3) * stage1_cols(3) - 2 * radius);
-    const int strips1 = ceil_div(w, stage1_threads(1) * stage1_cols(1) - 2 * radius);
+    // stage-1 strips: stage1_threads x stage1_cols columns, at least r of them halo on either side.
+    // The left halo and the output width are multiples of 16 (a 16-lane row of the per-pixel phase
+    // is then one aligned 16-column block of the image); a halo of a whole wave on either side is
+    // taken where it costs no strip (two of the strip's wave-iterations then have nothing to do, see
+    // the kernel).  Debug option "gf_s1_legacy_strips": halo r on either side (rounds 1-5).
+    struct StripGeom {
+        int hl, out_w, strips;
+    };
+    auto strip_geometry = [&](int scn) {
+        const int acw = stage1_threads(scn) * stage1_cols(scn);
+        StripGeom g;
+        if (debug_get(kDbgGfS1LegacyStrips)) {
+            g.hl = radius;
+            g.out_w = acw - 2 * radius;
+        } else {
+            g.hl = (radius + 15) & ~15;
+            g.out_w = (acw - g.hl - radius) & ~15;
+            if (radius <= 64 && ceil_div(w, acw - 128) <= ceil_div(w, g.out_w)) {
+                g.hl = 64;
+                g.out_w = acw - 128;
+            }
+        }
+        g.strips = ceil_div(w, g.out_w);
+        return g;
+    };
+    const StripGeom geo3 = strip_geometry(3), geo1 = strip_geometry(1);
+    const int strips3 = geo3.strips, strips1 = geo1.strips;
 
     // 3-channel sources: find the images whose channels are identical (see the file header)
     int *colour_all = nullptr;
@@ -1336,18 +1359,20 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
     do {                                                                                           \
         if (src_cn == 3) {                                                                         \
             hipLaunchKernelGGL((gf_stage1_kernel<3, 3, MODE>), ga3, dim3(stage1_threads(3)), pad3, st, \
-                               g0, s0, ab, h, w, radius, eps_f, eps_small, seg_rows3, colour, gs, 3); \
+                               g0, s0, ab, h, w, radius, eps_f, eps_small, seg_rows3, colour, gs, 3, \
+                               geo3.hl, geo3.out_w);                                               \
             if (cmp != nullptr)                                                                    \
                 hipLaunchKernelGGL((gf_stage1_kernel<1, 1, MODE>), ga1, dim3(stage1_threads(1)), pad1, \
                                    st, g0, cmp, ab, h, w, radius, eps_f, eps_small, seg_rows1,      \
-                                   colour, gs, 3);                                                 \
+                                   colour, gs, 3, geo1.hl, geo1.out_w);                            \
             else                                                                                   \
                 hipLaunchKernelGGL((gf_stage1_kernel<1, 3, MODE>), ga1, dim3(stage1_threads(1)), pad1, \
                                    st, g0, s0, ab, h, w, radius, eps_f, eps_small, seg_rows1,       \
-                                   colour, gs, 3);                                                 \
+                                   colour, gs, 3, geo1.hl, geo1.out_w);                            \
         } else {                                                                                   \
             hipLaunchKernelGGL((gf_stage1_kernel<1, 1, MODE>), ga1, dim3(stage1_threads(1)), pad1, st, \
-                               g0, s0, ab, h, w, radius, eps_f, eps_small, seg_rows1, colour, gs, 1); \
+                               g0, s0, ab, h, w, radius, eps_f, eps_small, seg_rows1, colour, gs, 1, \
+                               geo1.hl, geo1.out_w);                                               \
         }                                                                                          \
     } while (0)
         if (debug_get(kDbgGfExpSkip) & 1)
