@@ -293,6 +293,44 @@ __global__ __launch_bounds__(256) void gf_grey_probe_kernel(const uint8_t *__res
 //   kS1Reuse   only the 4*SCN src quantities are box-summed; the guide half is read from gs
 //              (requested at the top of a row, used at its end)          - later passes
 enum { kS1Full = 0, kS1Keep = 1, kS1Reuse = 2 };
+
+// "Exact rows" (rf_gf_fused.hpp): what stage 1 leaves for a stage 2 without a row walk.
+//   xf    [img * groups + group][row][plane 0..3][nb]  double: the sum of the plane's 16 values of
+//         image columns 16 b .. 16 b + 15 of that row (nb = w / 16), formed as a butterfly over the 16
+//         lanes that hold them (ds_swizzle: the LDS crossbar, no LDS memory).  In a row that passes
+//         the exactness test every partial sum is exact, so the order is immaterial; in a row that
+//         does not, nobody reads them.
+//   xstat [img * groups + group][row][strip * 8 + wave * 2 + half]  two packed words per half-wave:
+//         {alpha_0..2 jointly, beta}, each (top 16 bits of the largest magnitude's bit pattern << 1)
+//         << 16 | 0xffff - (top 16 bits of the smallest non-zero magnitude's (bits << 1) - 2).
+//         gf_exact_rows_kernel turns a row's words into its exactness flag.
+struct GfExactOut {
+    double *xf;
+    uint2 *xstat;
+    int nb, slots;  // 16-column blocks per row; statistic slots per row (strips x 8)
+};
+template <int PATTERN>
+__device__ __forceinline__ double swizzle_add(double d)
+{
+    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(d), PATTERN);
+    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(d), PATTERN);
+    return d + __hiloint2double(hi, lo);
+}
+template <int PATTERN>
+__device__ __forceinline__ uint32_t swizzle_pkmax(uint32_t v)
+{
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    const uint32_t o = (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, PATTERN);
+    u16x2 a, b;
+    __builtin_memcpy(&a, &v, 4);
+    __builtin_memcpy(&b, &o, 4);
+    const u16x2 m = __builtin_elementwise_max(a, b);
+    uint32_t r;
+    __builtin_memcpy(&r, &m, 4);
+    return r;
+}
+// ds_swizzle bit-mask mode: lane' = ((lane & and) | or) ^ xor within 32 lanes
+constexpr int swz_xor(int x) { return (x << 10) | 0x1f; }
 // Diagnostic build only (-DRF_GF_S1_STAMP, tools/gf_s1_stamp.py): shader cycles per phase of the row
 // loop, summed over waves, in a buffer of their own; no output depends on them.
 #ifdef RF_GF_S1_STAMP
@@ -306,12 +344,17 @@ __device__ unsigned long long g_s1_stamps[16];
 #else
 #define RF_S1_STAMP(i) do { } while (0)
 #endif
-template <int SCN, int SPX, int MODE>
-__global__ __launch_bounds__(stage1_threads(SCN)) void gf_stage1_kernel(
+// (waves per SIMD: the one-channel kernel is built for four - 128 registers -, which the exact-row
+//  additions would otherwise miss by one register; the three-channel kernel for three)
+template <int SCN, int SPX, int MODE, bool EXACT = false>
+__global__ __launch_bounds__(stage1_threads(SCN))
+    __attribute__((amdgpu_waves_per_eu(SCN == 1 ? 4 : 3))) void gf_stage1_kernel(
     const uint8_t *__restrict__ guide, const uint8_t *__restrict__ src, float *__restrict__ ab,
     int h, int w, int radius, float eps_f, int eps_small, int seg_rows,
-    const int *__restrict__ colour, float *__restrict__ gs, int ab_groups, int hl, int out_w)
+    const int *__restrict__ colour, float *__restrict__ gs, int ab_groups, int hl, int out_w,
+    const GfExactOut xo)
 {
+    static_assert(!EXACT || MODE == kS1Full, "exact rows: plain stage 1 only");
     // hl, out_w: the strip's geometry - its kACW columns are image columns xs - hl .. xs - hl + kACW - 1
     // (xs = strip index x out_w), of which columns hl .. hl + out_w - 1 are its outputs; hl >= radius
     // and kACW - hl - out_w >= radius (rf_gf_u8 picks them, see gf_strip_geometry)
@@ -511,6 +554,18 @@ __global__ __launch_bounds__(stage1_threads(SCN)) void gf_stage1_kernel(
         RF_S1_STAMP(3);
         __syncthreads();
         RF_S1_STAMP(4);
+        // exact rows: largest magnitude (as a float) and smallest non-zero magnitude (as (bits << 1) - 2,
+        // which sends a zero to the top) of the row's alpha planes jointly and of its beta plane, per
+        // src channel, over this lane's columns
+        float xmx_a[SCN], xmx_b[SCN];
+        uint32_t xmn_a[SCN], xmn_b[SCN];
+        if (EXACT) {
+#pragma unroll
+            for (int sc = 0; sc < SCN; sc++) {
+                xmx_a[sc] = xmx_b[sc] = 0.f;
+                xmn_a[sc] = xmn_b[sc] = 0xffffffffu;
+            }
+        }
 #pragma unroll
         for (int k = 0; k < kACols; k++) {
             const int c = tidp + kAThreads * k;
@@ -547,7 +602,62 @@ __global__ __launch_bounds__(stage1_threads(SCN)) void gf_stage1_kernel(
                                    __float_as_uint(ab_px[4 * sc + 2]), __float_as_uint(ab_px[4 * sc + 3])};
                 __builtin_amdgcn_raw_buffer_store_b128(o, rab, x * 16, 0, 0);
             }
+            if (EXACT) {
+                // (col_ok is uniform over a 16-lane row here: hl, out_w and w are multiples of 16)
+#pragma unroll
+                for (int sc = 0; sc < SCN; sc++) {
+                    const float a0 = ab_px[4 * sc], a1 = ab_px[4 * sc + 1], a2 = ab_px[4 * sc + 2],
+                                bt = ab_px[4 * sc + 3];
+                    xmx_a[sc] = fmaxf(fmaxf(xmx_a[sc], fabsf(a0)), fmaxf(fabsf(a1), fabsf(a2)));
+                    xmx_b[sc] = fmaxf(xmx_b[sc], fabsf(bt));
+                    xmn_a[sc] = min(min(xmn_a[sc], (__float_as_uint(a0) << 1) - 2u),
+                                    min((__float_as_uint(a1) << 1) - 2u, (__float_as_uint(a2) << 1) - 2u));
+                    xmn_b[sc] = min(xmn_b[sc], (__float_as_uint(bt) << 1) - 2u);
+#ifndef RF_X_NOF
+                    double d[4];
+#pragma unroll
+                    for (int p = 0; p < 4; p++) {
+                        d[p] = (double)ab_px[4 * sc + p];
+                        d[p] = swizzle_add<swz_xor(1)>(d[p]);
+                        d[p] = swizzle_add<swz_xor(2)>(d[p]);
+                        d[p] = swizzle_add<swz_xor(4)>(d[p]);
+                        d[p] = swizzle_add<swz_xor(8)>(d[p]);
+                    }
+                    // lane j < 4 of the 16-lane row stores plane j's sum
+                    const double d01 = (lane & 1) ? d[1] : d[0], d23 = (lane & 1) ? d[3] : d[2];
+                    const double dsel = (lane & 2) ? d23 : d01;
+                    if ((lane & 15) < 4) {
+                        double *xr = xo.xf + (((size_t)blockIdx.z * ab_groups + sc) * h + y) * 4 * xo.nb;
+                        xr[(lane & 3) * xo.nb + (x >> 4)] = dsel;
+                    }
+#endif
+                }
+            }
         }
+#ifndef RF_X_NOSTAT
+        if (EXACT) {
+            // the half-wave's statistics: five butterfly steps over packed 16-bit fields (maximum of
+            // the largest, maximum of the inverted smallest), lanes 0 and 32 store
+#pragma unroll
+            for (int sc = 0; sc < SCN; sc++) {
+                uint32_t wa = ((__float_as_uint(xmx_a[sc]) >> 15) << 16) | (0xffffu - (xmn_a[sc] >> 16));
+                uint32_t wb = ((__float_as_uint(xmx_b[sc]) >> 15) << 16) | (0xffffu - (xmn_b[sc] >> 16));
+                wa = swizzle_pkmax<swz_xor(1)>(wa);
+                wb = swizzle_pkmax<swz_xor(1)>(wb);
+                wa = swizzle_pkmax<swz_xor(2)>(wa);
+                wb = swizzle_pkmax<swz_xor(2)>(wb);
+                wa = swizzle_pkmax<swz_xor(4)>(wa);
+                wb = swizzle_pkmax<swz_xor(4)>(wb);
+                wa = swizzle_pkmax<swz_xor(8)>(wa);
+                wb = swizzle_pkmax<swz_xor(8)>(wb);
+                wa = swizzle_pkmax<swz_xor(16)>(wa);
+                wb = swizzle_pkmax<swz_xor(16)>(wb);
+                if ((lane & 31) == 0)
+                    xo.xstat[(((size_t)blockIdx.z * ab_groups + sc) * h + y) * xo.slots + blockIdx.x * 8 +
+                             wave * 2 + (lane >> 5)] = make_uint2(wa, wb);
+            }
+        }
+#endif
         RF_S1_STAMP(5);
         add_row(y - radius, RowOut{});
         RF_S1_STAMP(6);
@@ -990,6 +1100,14 @@ size_t gf_per_img_row_walk(size_t npx, int np, int nb, int h)
 {
     return (size_t)np * (npx * sizeof(float) + (size_t)nb * h * sizeof(double));
 }
+// exact rows: per image and plane group the statistics of stage 1 (8 B per half-wave and row; a strip
+// has at least 256 output columns for every radius the 8-bit kernels take), a flag byte and a list
+// entry per row, the list's length
+size_t gf_exact_extra(int np, int h, int w)
+{
+    const size_t slots = (size_t)ceil_div(w, 256) * 8;
+    return (((size_t)(np / 4) * ((size_t)h * (slots * 8 + 8) + 16)) + 255) & ~(size_t)255;
+}
 constexpr size_t kGfSyncBytes = 256;
 // radii above this run the float kernels (uint32 window sums: (2r+1)^2 * 255^2 < 2^32; strip width)
 constexpr int kGfMaxRadiusU8 = 120;
@@ -1032,9 +1150,14 @@ extern "C" size_t rf_gf_workspace_bytes(int n, int h, int w, int guide_cn, int s
     size_t per_img = rf::gf_per_img_two_kernel((size_t)h * w, 4 * src_cn);
     if (radius > rf::kGfMaxRadiusU8)  // float kernels on float copies of the images (rf_gf_u8)
         per_img = rf::gf_per_img_via_f32((size_t)h * w, src_cn);
-    if (radius >= 1 && radius <= rf::kGfFusedMaxRadius)
+    if (radius >= 1 && radius <= rf::kGfFusedMaxRadius) {
         per_img = std::max(per_img, rf::gf_per_img_chained((size_t)h * w, 4 * src_cn,
                                                            rf::ceil_div(w, rf::kSB), h, radius));
+        per_img = std::max(per_img, rf::gf_per_img_row_walk((size_t)h * w, 4 * src_cn,
+                                                            rf::ceil_div(w, rf::kSB), h) +
+                                        rf::gf_exact_extra(4 * src_cn, h, w) +
+                                        (((size_t)h * w + 15) & ~(size_t)15));
+    }
     // enough images in flight to fill the chip and to make the tails of the launches small: capped
     // at 1/8 of the device's memory, at most 32 GiB (6 GiB when no device can be asked).  C5 shard
     // (128 x 4K, 3 passes): round 2 91.5 ms with 6 GiB (13 images per chunk), 86.6 ms with 16 GiB (37);
@@ -1171,8 +1294,17 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
          workspace_bytes - header >= per_img_fused + (keep_gs ? gs_bytes : 0) + cmp_want)
             ? cmp_want
             : 0;
-    const size_t per_img_used =
-        (fused ? per_img_fused : per_img) + (keep_gs ? gs_bytes : 0) + cmp_bytes;
+    // Exact rows (rf_gf_fused.hpp): rows whose alpha/beta pass the exactness test need no row walk -
+    // stage 1 leaves block sums and per-row statistics, the rows that fail are listed and walked, the
+    // column walk starts its chains from the block sums.  Needs a width that is a multiple of 16 and
+    // room for the statistics; debug option "gf_no_exact" keeps the row walk for every row.
+    const size_t exact_bytes = gf_exact_extra(np, h, w);
+    const bool exact =
+        fused && !chained && !keep_gs && w % 16 == 0 && h <= kGfExactMaxH && !debug_get(kDbgGfNoExact) &&
+        !debug_get(kDbgGfS1LegacyStrips) &&
+        workspace_bytes - header >= per_img_fused + cmp_bytes + exact_bytes;
+    const size_t per_img_used = (fused ? per_img_fused : per_img) + (keep_gs ? gs_bytes : 0) +
+                                cmp_bytes + (exact ? exact_bytes : 0);
     int chunk = (int)std::min<size_t>((size_t)n, (workspace_bytes - header) / per_img_used);
     if (chunk > 16383)
         chunk = 16383;
@@ -1209,6 +1341,9 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
     };
     const StripGeom geo3 = strip_geometry(3), geo1 = strip_geometry(1);
     const int strips3 = geo3.strips, strips1 = geo1.strips;
+    const int xslots = std::max(strips1, strips3) * 8;  // exact rows: statistic slots per row
+    const int mask_words = ceil_div(h, 32);
+    const GfStateLayout lay = exact ? GfStateLayout{nb, 1, 4 * nb} : GfStateLayout{nb * h, h, 1};
 
     // 3-channel sources: find the images whose channels are identical (see the file header)
     int *colour_all = nullptr;
@@ -1231,6 +1366,9 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
         double *rows;
         float *ab, *gs;
         uint8_t *cmp;
+        uint2 *xstat;            // exact rows: statistics, list and its lengths, flag bitmask
+        unsigned *rowmask;
+        int *xlist, *xcount;
         GfChain xc;
         const uint8_t *g0;
         uint8_t *d0;
@@ -1273,6 +1411,18 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
         P.cmp = cmp_bytes ? reinterpret_cast<uint8_t *>(P.ab + (size_t)m * np * npx) +
                                 (keep_gs ? (size_t)m * gs_bytes : 0)
                           : nullptr;
+        P.xstat = nullptr;
+        P.rowmask = nullptr;
+        P.xlist = P.xcount = nullptr;
+        if (exact) {
+            char *xb = reinterpret_cast<char *>(P.ab + (size_t)m * np * npx) +
+                       (keep_gs ? (size_t)m * gs_bytes : 0) + (size_t)m * cmp_bytes;
+            const size_t rows_all = (size_t)m * src_cn * h;
+            P.xstat = reinterpret_cast<uint2 *>(xb);
+            P.xlist = reinterpret_cast<int *>(P.xstat + rows_all * xslots);
+            P.xcount = P.xlist + rows_all;  // [m x groups] lengths, then [m x groups][mask_words] flags
+            P.rowmask = reinterpret_cast<unsigned *>(P.xcount + (size_t)m * src_cn);
+        }
         P.g0 = guide + (size_t)i0 * npx * 3;
         P.d0 = dst + (size_t)i0 * npx * src_cn;
         // Rows per stage-1 segment (m_fill: the images whose stage 1 is in flight on the device
@@ -1355,43 +1505,56 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
         const uint8_t *g0 = P.g0, *cmp = P.cmp;
         const uint8_t *s0 = (it == 0 ? src : (const uint8_t *)dst) + (size_t)P.i0 * npx * src_cn;
         const dim3 ga3(strips3, ceil_div(h, seg_rows3), m), ga1(strips1, ceil_div(h, seg_rows1), m);
-#define RF_GF_STAGE1(MODE)                                                                         \
+        const GfExactOut xo = {P.rows, P.xstat, nb, xslots};
+#define RF_GF_STAGE1(MODE, EX)                                                                     \
     do {                                                                                           \
         if (src_cn == 3) {                                                                         \
-            hipLaunchKernelGGL((gf_stage1_kernel<3, 3, MODE>), ga3, dim3(stage1_threads(3)), pad3, st, \
-                               g0, s0, ab, h, w, radius, eps_f, eps_small, seg_rows3, colour, gs, 3, \
-                               geo3.hl, geo3.out_w);                                               \
+            hipLaunchKernelGGL((gf_stage1_kernel<3, 3, MODE, EX>), ga3, dim3(stage1_threads(3)), pad3, \
+                               st, g0, s0, ab, h, w, radius, eps_f, eps_small, seg_rows3, colour,  \
+                               gs, 3, geo3.hl, geo3.out_w, xo);                                    \
             if (cmp != nullptr)                                                                    \
-                hipLaunchKernelGGL((gf_stage1_kernel<1, 1, MODE>), ga1, dim3(stage1_threads(1)), pad1, \
-                                   st, g0, cmp, ab, h, w, radius, eps_f, eps_small, seg_rows1,      \
-                                   colour, gs, 3, geo1.hl, geo1.out_w);                            \
+                hipLaunchKernelGGL((gf_stage1_kernel<1, 1, MODE, EX>), ga1, dim3(stage1_threads(1)), \
+                                   pad1, st, g0, cmp, ab, h, w, radius, eps_f, eps_small,          \
+                                   seg_rows1, colour, gs, 3, geo1.hl, geo1.out_w, xo);             \
             else                                                                                   \
-                hipLaunchKernelGGL((gf_stage1_kernel<1, 3, MODE>), ga1, dim3(stage1_threads(1)), pad1, \
-                                   st, g0, s0, ab, h, w, radius, eps_f, eps_small, seg_rows1,       \
-                                   colour, gs, 3, geo1.hl, geo1.out_w);                            \
+                hipLaunchKernelGGL((gf_stage1_kernel<1, 3, MODE, EX>), ga1, dim3(stage1_threads(1)), \
+                                   pad1, st, g0, s0, ab, h, w, radius, eps_f, eps_small,           \
+                                   seg_rows1, colour, gs, 3, geo1.hl, geo1.out_w, xo);             \
         } else {                                                                                   \
-            hipLaunchKernelGGL((gf_stage1_kernel<1, 1, MODE>), ga1, dim3(stage1_threads(1)), pad1, st, \
-                               g0, s0, ab, h, w, radius, eps_f, eps_small, seg_rows1, colour, gs, 1, \
-                               geo1.hl, geo1.out_w);                                               \
+            hipLaunchKernelGGL((gf_stage1_kernel<1, 1, MODE, EX>), ga1, dim3(stage1_threads(1)), pad1, \
+                               st, g0, s0, ab, h, w, radius, eps_f, eps_small, seg_rows1, colour,  \
+                               gs, 1, geo1.hl, geo1.out_w, xo);                                    \
         }                                                                                          \
     } while (0)
         if (debug_get(kDbgGfExpSkip) & 1)
             ;  // timing experiment: no stage 1 (results wrong)
+        else if (exact)
+            RF_GF_STAGE1(kS1Full, true);
         else if (!keep_gs)
-            RF_GF_STAGE1(kS1Full);
+            RF_GF_STAGE1(kS1Full, false);
         else if (it == 0)
-            RF_GF_STAGE1(kS1Keep);
+            RF_GF_STAGE1(kS1Keep, false);
         else
-            RF_GF_STAGE1(kS1Reuse);
+            RF_GF_STAGE1(kS1Reuse, false);
 #undef RF_GF_STAGE1
     };
     auto part_stage2 = [&](const Part &P, int it) {
         hipStream_t st = P.st;
         const int m = P.m;
         if (fused) {
+            GfExact xr = {nullptr, nullptr, nullptr, 0, 0};
+            if (exact) {
+                // the rows that fail the exactness test: flagged for the column walk, listed for the row walk
+                (void)hipMemsetAsync(P.xcount, 0, sizeof(int) * (size_t)m * src_cn * (1 + mask_words), st);
+                hipLaunchKernelGGL(gf_exact_rows_kernel<0>, dim3((unsigned)ceil_div(h, 256), (unsigned)(m * src_cn)),
+                                   dim3(256), 0, st, P.xstat, h, xslots, strips1 * 8, strips3 * 8, src_cn,
+                                   debug_get(kDbgGfExactAllFlagged) ? -1 : gf_exact_limit(radius),
+                                   P.colour, P.rowmask, mask_words, P.xlist, P.xcount);
+                xr = GfExact{P.rowmask, P.xlist, P.xcount, mask_words, 1};
+            }
             const GfFusedArgs fa = {P.ab, P.rows, P.g0, P.d0, m, h, w, nb, src_cn, P.colour, st, P.xc,
                                     debug_get(kDbgGfExpSkip),
-                                    it + 1 < iterations ? P.cmp : nullptr};
+                                    it + 1 < iterations ? P.cmp : nullptr, lay, xr};
             fused_launch(fa);
             return;
         }

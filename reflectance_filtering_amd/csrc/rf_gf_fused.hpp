@@ -31,6 +31,94 @@ constexpr int kSB = 16;     // columns per state block and per column-walk workg
 constexpr int kBRows = 64;  // rows per row-walk workgroup (one lane per row)
 constexpr int kGsFloatsPublic = 9;  // floats per pixel of the guide record kept by iterated calls
 
+// ------------------------------------------------------------------------------------------
+// "Exact rows" (round 6).  RowSum<float,double> is a chain of double additions whose ORDER is part of
+// the contract only as far as it rounds.  Sufficient test for a row of one plane (or of several
+// planes taken together): let 2^e be the weight of the last mantissa bit of its smallest non-zero
+// magnitude (every value of the row is then a multiple of 2^e, zeros included) and M its largest
+// magnitude; if ks * M <= 2^(e + 53), then every partial sum of at most ks of the row's values
+// (border-reflected repeats included) is a multiple of 2^e below 2^(e + 53) in magnitude, i.e. a
+// double: the chain's first ks additions, every difference `entering - leaving` (|.| <= 2 M) and
+// every `s += difference` (a window sum again) are exact, the chain holds the mathematically exact
+// window sum at every column, and ANY order of exact additions over subsets of a window gives the
+// same doubles.  In exponent fields (E = bits >> 23, a denormal's taken as 1):
+//     max(Emax, 1) - max(Emin, 1) <= 29 - ceil(log2 ks)         (gf_exact_limit)
+// because M < 2^(Emax - 126) and e = Emin - 150.
+//
+// For such rows stage 2 needs no row walk: stage 1 leaves the sum of every aligned 16-column block
+// (xf, see rf_gf.hip), and the column walk rebuilds the row sum at its block's first column 16 b as
+//     prefix of block b + q up to column 16 b + R   (= F[b + q] - the c0' entering operands behind it)
+//   + F[b - q] + ... + F[b + q - 1]                  (block indices reflected like columns)
+//   + suffix of block b - q - 1 from column 16 b - R (= its first c0 leaving operands)
+// with q = R / 16, c0 = R % 16, c0' = 15 - c0 - every intermediate a sum over a subset of the window.
+// Rows that fail the test are listed by gf_exact_rows_kernel (from the per-half-wave statistics
+// stage 1 leaves), walked sequentially by gf_rowstate_kernel in its list mode, which writes the
+// chain's true value into slot b of the same array, and the column walk takes that slot as it is.
+// Needs w % 16 == 0 (a reflected block is a block); other widths take the row walk for every row.
+// ------------------------------------------------------------------------------------------
+__host__ __device__ inline int gf_exact_limit(int radius)
+{
+    const int ks = 2 * radius + 1;
+    int lim = 29;
+    while ((1 << (29 - lim)) < ks)
+        lim--;
+    return lim;
+}
+// Layout of the block sums / row states: element (plane, block, row) of a plane group sits at
+// plane * sp + block * sb + row * sr doubles.  Row walk: [plane][nb][h]; exact rows: [row][plane][nb].
+struct GfStateLayout {
+    int sp, sb, sr;
+};
+constexpr int kGfExactMaxH = 16384;  // rows of an image the column walk's flag bitmask (LDS) holds
+struct GfExact {
+    const unsigned *rowmask;  // [img * groups + group][mask_words]: bit r = row r takes its state from the row walk
+    const int *list;          // [img * groups + group][h]: the flagged rows, count[..] of them
+    const int *count;
+    int mask_words;           // ceil(h / 32)
+    int on;                   // 0: every row takes the row walk (rowmask, list, count unused)
+};
+
+// One lane per (plane group, row): the row's exactness flag from the statistics of stage 1.
+//   stats [img * groups + group][row][slots] {alpha word, beta word}: (max16 << 16) | (0xffff - min16)
+// slots = stride of a row's statistics, used1 / used3 = how many of them the one- / three-channel
+// stage 1 writes.  grid (ceil(h / 256), images x groups); count[] and rowmask[] zeroed beforehand.
+template <int kHeaderOnly = 0>
+__global__ __launch_bounds__(256) void gf_exact_rows_kernel(const uint2 *__restrict__ stats, int h,
+                                                            int slots, int used1, int used3,
+                                                            int groups, int limit,
+                                                            const int *__restrict__ colour,
+                                                            unsigned *__restrict__ rowmask,
+                                                            int mask_words, int *__restrict__ list,
+                                                            int *__restrict__ count)
+{
+    const int ig = blockIdx.y, img = ig / groups, g = ig - img * groups;
+    if (colour != nullptr && g >= 1 && colour[img] == 0)
+        return;  // grey 3-channel image: only its first channel's planes exist
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= h)
+        return;
+    // (the slots the image's stage-1 instantiation wrote: its strips x 8)
+    const int used = (colour != nullptr && colour[img] != 0) ? used3 : used1;
+    const uint2 *S = stats + ((size_t)ig * h + row) * slots;
+    uint32_t wa = 0, wb = 0;
+    for (int i = 0; i < used; i++) {
+        const uint2 v = S[i];
+        wa = max(wa & 0xffff0000u, v.x & 0xffff0000u) | max(wa & 0xffffu, v.x & 0xffffu);
+        wb = max(wb & 0xffff0000u, v.y & 0xffff0000u) | max(wb & 0xffffu, v.y & 0xffffu);
+    }
+    auto fails = [&](uint32_t wd) {
+        const int mx16 = (int)(wd >> 16), mn16 = 0xffff - (int)(wd & 0xffffu);
+        if (mx16 == 0)
+            return false;  // an all-zero row
+        const int emax = max(mx16 >> 8, 1), emin = max(mn16 >> 8, 1);
+        return emax - emin > limit;
+    };
+    if (fails(wa) || fails(wb)) {
+        atomicOr(&rowmask[(size_t)ig * mask_words + (row >> 5)], 1u << (row & 31));
+        list[(size_t)ig * h + atomicAdd(&count[ig], 1)] = row;
+    }
+}
+
 // Does this workgroup's instantiation apply to image img?  (colour == nullptr: no choice to make)
 template <int SCN>
 __device__ inline bool wrong_variant(const int *__restrict__ colour, int img)
@@ -78,8 +166,12 @@ __global__ __launch_bounds__(256) void gf_rowstate_kernel(const float *__restric
                                                           double *__restrict__ states, int h, int w,
                                                           int row_blocks, int np,
                                                           const int *__restrict__ colour, int src_np,
-                                                          int nb, int streaming)
+                                                          int nb, int streaming, const GfStateLayout lay,
+                                                          const GfExact xr)
 {
+    // List mode (xr.on; exact rows): the workgroup's 64 lanes are the entries 64 rb .. 64 rb + 63 of the
+    // plane group's list of flagged rows instead of 64 consecutive rows; workgroups past the end of
+    // the list exit at once - on typical images a fraction of a percent of the rows is listed.
     constexpr int KS = 2 * R + 1;
     constexpr int F = (KS + 15) & ~15;
     constexpr int NCH = F / 16;
@@ -98,19 +190,29 @@ __global__ __launch_bounds__(256) void gf_rowstate_kernel(const float *__restric
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // the wave's plane of the group
     const int row0 = (blockIdx.x - grp * row_blocks) * kBRows;
+    const int ig = img * ng + gq;
+    const int listed = xr.on ? xr.count[ig] - row0 : 0;  // list entries from this workgroup's first one on
+    if (xr.on && listed <= 0)
+        return;
+    const int *rlist = xr.list + (size_t)ig * h + row0;
+    // image row of the workgroup's row slot r (loads of slots past the end repeat the last one)
+    auto slot_row = [&](int r) __attribute__((always_inline)) {
+        return xr.on ? rlist[min(r, listed - 1)] : min(row0 + r, h - 1);
+    };
     const float4 *S4 =
         reinterpret_cast<const float4 *>(planes + ((size_t)img * src_np + gq * 4) * h * w);
-    double *ST = states + ((size_t)img * np + gq * 4 + wv) * nb * h + row0 + lane;
+    double *ST = states + ((size_t)img * np + gq * 4) * nb * h + (size_t)wv * lay.sp +
+                 (size_t)slot_row(lane) * lay.sr;
     const int total = w + 2 * R + PAD;  // steps
     // loader role: the workgroup fetches the chunk's 64 rows x 16 columns as 1024 float4 (all
     // four planes of a pixel), thread t the pixels t, t + 256, ...: 16 consecutive threads read
     // 256 contiguous bytes of one image row
     const int cc = tid & 15;
-    const bool row_ok = row0 + lane < h;
+    const bool row_ok = xr.on ? lane < listed : row0 + lane < h;
     uint32_t srow[4];
 #pragma unroll
     for (int k = 0; k < 4; k++)
-        srow[k] = (uint32_t)min(row0 + ((tid + 256 * k) >> 4), h - 1) * (uint32_t)w;
+        srow[k] = (uint32_t)slot_row((tid + 256 * k) >> 4) * (uint32_t)w;
 
     float4 preA[4], preB[4];
     // (a chunk away from both ends of the row needs no border arithmetic; pixel offsets fit 32
@@ -179,7 +281,7 @@ __global__ __launch_bounds__(256) void gf_rowstate_kernel(const float *__restric
                     const int c = 8 * hh + c8;
                     s += d[c8];
                     if (((c - PAD - KS + 1) & (kSB - 1)) == 0 && row_ok)
-                        ST[(size_t)((t0 + c - PAD - KS + 1) >> 4) * h] = s;
+                        ST[(size_t)((t0 + c - PAD - KS + 1) >> 4) * lay.sb] = s;
                 }
             }
 #pragma unroll
@@ -201,7 +303,7 @@ __global__ __launch_bounds__(256) void gf_rowstate_kernel(const float *__restric
                     fifo[tp] = e;
                     const int o = t0 + c - PAD - KS + 1;  // output column of this RowSum
                     if (o >= 0 && (o & (kSB - 1)) == 0 && row_ok)
-                        ST[(size_t)(o >> 4) * h] = s;
+                        ST[(size_t)(o >> 4) * lay.sb] = s;
                 }
             }
         }
@@ -403,11 +505,13 @@ __global__ __launch_bounds__(128, (R <= 64 ? 2 : 1)) void gf_colwalk_kernel(
     const float *__restrict__ ab, const double *__restrict__ states,
     const uint8_t *__restrict__ guide, uint8_t *__restrict__ dst, int h, int w, int nb,
     int n_pairs, int spx, const int *__restrict__ colour, const GfChain xc,
-    uint8_t *__restrict__ compact)
+    uint8_t *__restrict__ compact, const GfStateLayout lay, const GfExact xr)
 {
     using G = WalkGeom<R>;
     constexpr int M = G::M, T = G::T;
     constexpr int KS = 2 * R + 1;
+    // exact rows (xr.on): the row chains start from block sums instead of stored states, see the top
+    constexpr int XQ = R / 16, XC0 = R % 16, NF = 2 * XQ + 1;
     constexpr int FL = G::fifo_len();
     constexpr int NL = (T + 3) / 4;  // operand load instructions per sub-tile and side (4 rows each)
     // work item = (image, column block) pair x src channel.  Workgroups are dealt round-robin to
@@ -419,6 +523,7 @@ __global__ __launch_bounds__(128, (R <= 64 ? 2 : 1)) void gf_colwalk_kernel(
     __shared__ double sumx[64];
     __shared__ int turn;  // next sub-tile whose column phase may run
     __shared__ int ticket;
+    __shared__ unsigned xmask[CHAINED ? 1 : kGfExactMaxH / 32];  // exact rows: the image's flagged rows
 
     constexpr bool chained = CHAINED;
     const int lane = threadIdx.x & 63;
@@ -429,7 +534,15 @@ __global__ __launch_bounds__(128, (R <= 64 ? 2 : 1)) void gf_colwalk_kernel(
         if (chained)
             ticket = (int)atomicAdd(&xc.sync[blockIdx.x & 7], 1u);
     }
-    __syncthreads();  // the only barrier: both waves see turn = 0 (and the ticket)
+    if (!chained && xr.on) {
+        // (the work item is known from blockIdx alone in this form: see below)
+        const int per_xcd_ = (n_pairs + 7) >> 3, q_ = (int)(blockIdx.x >> 3);
+        const int pair_ = min((int)(blockIdx.x & 7) * per_xcd_ + q_ / spx, n_pairs - 1);
+        const unsigned *gm = xr.rowmask + (size_t)((pair_ / nb) * spx + q_ % spx) * xr.mask_words;
+        for (int i = threadIdx.x; i < xr.mask_words; i += 128)
+            xmask[i] = gm[i];
+    }
+    __syncthreads();  // the only barrier: both waves see turn = 0 (and the ticket, and the flags)
     int s_ch, b, img;
     if (chained) {
         const int qx = (int)(blockIdx.x & 7), m_img = n_pairs / nb;
@@ -476,7 +589,16 @@ __global__ __launch_bounds__(128, (R <= 64 ? 2 : 1)) void gf_colwalk_kernel(
     // start of the lane's row chain: the stored state at column 16 b (row-walk form), or - chained -
     // the sum at column 16 b - 1: for block 0 the head sums, else what block b - 1 published
     const double *Ps = chained ? xc.head + ((size_t)img * np + 4 * s_ch + min(cp, 3)) * h
-                               : stg + ((size_t)min(cp, 3) * nb + b) * h;
+                               : stg + (size_t)min(cp, 3) * lay.sp + (size_t)b * lay.sb;
+    const bool exact = !chained && xr.on != 0;
+    // (an interior block's 2q + 1 sums are consecutive doubles: fetched 16 bytes at a time)
+    const bool xinner = b - XQ >= 0 && b + XQ < nb && lay.sb == 1;
+    // exact rows: the 2q + 1 blocks b - q .. b + q whose sums a chain starts from (reflected like
+    // columns; slot b - the middle one - holds the true state of a row the row walk had to take)
+    int xkb[NF];
+#pragma unroll
+    for (int i = 0; i < NF; i++)
+        xkb[i] = (border_interpolate(b - XQ + i, nb, RF_BORDER_REFLECT) - b) * lay.sb;
     const double scale = 1.0 / (double)(KS * KS);
     const int total = h + 2 * R;  // padded rows
     const int jmax = total - 1;
@@ -518,6 +640,11 @@ __global__ __launch_bounds__(128, (R <= 64 ? 2 : 1)) void gf_colwalk_kernel(
     const int fr = lane >> 2, qd = lane & 3;  // flush role: row of the sub-tile, quad of columns
     float4 pe[NL], pl[NL];
     double pst = 0.0;
+    double pxf[NF];  // exact rows: the prefetched block sums (slot XQ: the state of a flagged row)
+    int pxflag = 0;
+#pragma unroll
+    for (int i = 0; i < NF; i++)
+        pxf[i] = 0.0;
     uint32_t gpre[3];  // guide bytes of the lane's four output pixels
     double SUM = 0.0;
     double fifo[FL];
@@ -546,8 +673,29 @@ __global__ __launch_bounds__(128, (R <= 64 ? 2 : 1)) void gf_colwalk_kernel(
             pe[i] = *reinterpret_cast<const float4 *>(abgb + (oe + ro));
             pl[i] = *reinterpret_cast<const float4 *>(abgb + (ol_ + ro));
         }
-        if (chain && !take)
-            pst = Ps[L.rowtab[slot][cl]];
+        if (chain && !take) {
+            const int row = L.rowtab[slot][cl];
+            if (exact) {
+                pxflag = (int)((xmask[row >> 5] >> (row & 31)) & 1u);
+                const double *pr = Ps + (size_t)row * lay.sr;
+                if (xinner) {
+                    typedef double d2_t __attribute__((ext_vector_type(2), aligned(8)));
+#pragma unroll
+                    for (int i = 0; i + 1 < NF; i += 2) {
+                        const d2_t v = *reinterpret_cast<const d2_t *>(pr + (i - XQ));
+                        pxf[i] = v.x;
+                        pxf[i + 1] = v.y;
+                    }
+                    pxf[NF - 1] = pr[XQ];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NF; i++)
+                        pxf[i] = pr[xkb[i]];
+                }
+            } else {
+                pst = Ps[(size_t)row * lay.sr];
+            }
+        }
     };
     // chained, b > 0: request the left neighbour's slot of sub-tile jj (two self-validating words)
     auto take_issue = [&](int jj) __attribute__((always_inline)) {
@@ -678,6 +826,11 @@ __global__ __launch_bounds__(128, (R <= 64 ? 2 : 1)) void gf_colwalk_kernel(
             }
         }
         double s = take ? take_sums(j) : pst;
+        double xfc[NF];
+#pragma unroll
+        for (int i = 0; i < NF; i++)
+            xfc[i] = pxf[i];
+        const int xflg = pxflag;
         RF_STAMP(1);  // wait for the operands (and every older store)
         store_pending();
         st_tj = 0;
@@ -697,6 +850,22 @@ __global__ __launch_bounds__(128, (R <= 64 ? 2 : 1)) void gf_colwalk_kernel(
 #pragma unroll
             for (int c = 1; c < kSB; c++)
                 d[c] = (double)L.u.st.E[lane][c] - (double)L.u.st.L[lane][c];
+            if (exact) {
+                // the window sum at column 16 b from block sums, every intermediate a sum over a
+                // subset of that window: prefix of block b + q, the 2q blocks in front of it, the
+                // suffix of block b - q - 1
+                double se = xfc[NF - 1];
+#pragma unroll
+                for (int c = 1; c <= 15 - XC0; c++)
+                    se -= (double)L.u.st.E[lane][c];
+#pragma unroll
+                for (int i = NF - 2; i >= 0; i--)
+                    se += xfc[i];
+#pragma unroll
+                for (int c = 1; c <= XC0; c++)
+                    se += (double)L.u.st.L[lane][c];
+                s = xflg ? xfc[XQ] : se;
+            }
             if (chained) {
                 // s is the sum at column 16 b - 1: one more step to column 16 b.  At the row's
                 // first output column nothing leaves the window yet (block 0: s = sum of ext[0 .. 2R-1])
@@ -852,6 +1021,8 @@ struct GfFusedArgs {
     GfChain chain;  // xst == nullptr: row-walk form (gf_rowstate_kernel + stored states)
     int exp_skip;  // timing experiments only (debug option "gf_exp_skip"): bit 1 no row states, bit 2 no column walk
     uint8_t *compact;  // not the last pass of an iterated call: grey 3-channel images go here, 1 B per pixel
+    GfStateLayout lay;  // where a (plane, block, row) state / block sum sits
+    GfExact xr;         // exact rows: flags and list of the rows that take the row walk (on = 0: all do)
 };
 typedef void (*GfFusedLaunch)(const GfFusedArgs &);
 GfFusedLaunch gf_fused_launcher(int radius);  // nullptr outside 1 .. kGfFusedMaxRadius
@@ -874,7 +1045,7 @@ void gf_fused_launch(const GfFusedArgs &a)
                 hipLaunchKernelGGL((gf_colwalk_kernel<R, true>),
                                    dim3(8u * (unsigned)((a.m + 7) / 8) * a.src_cn * a.nb), dim3(128),
                                    0, a.stream, a.ab, a.states, a.guide, a.dst, a.h, a.w, a.nb, pairs,
-                                   a.src_cn, a.colour, a.chain, a.compact);
+                                   a.src_cn, a.colour, a.chain, a.compact, a.lay, GfExact{nullptr, nullptr, nullptr, 0, 0});
         }
         return;
     }
@@ -882,11 +1053,12 @@ void gf_fused_launch(const GfFusedArgs &a)
         hipLaunchKernelGGL((gf_rowstate_kernel<R>), dim3((unsigned)(a.m * a.src_cn * row_blocks)),
                            dim3(256), 0, a.stream, a.ab, a.states, a.h, a.w, row_blocks, np, a.colour,
                            np, a.nb,
-                           (size_t)a.m * np * a.h * a.w * sizeof(float) > ((size_t)256 << 20) ? 1 : 0);
+                           (size_t)a.m * np * a.h * a.w * sizeof(float) > ((size_t)256 << 20) ? 1 : 0,
+                           a.lay, a.xr);
     if (!(a.exp_skip & 4))
         hipLaunchKernelGGL((gf_colwalk_kernel<R>), dim3(8u * (unsigned)((pairs + 7) / 8) * a.src_cn),
                        dim3(128), 0, a.stream, a.ab, a.states, a.guide, a.dst, a.h, a.w, a.nb, pairs,
-                       a.src_cn, a.colour, GfChain{nullptr, nullptr, nullptr}, a.compact);
+                       a.src_cn, a.colour, GfChain{nullptr, nullptr, nullptr}, a.compact, a.lay, a.xr);
 }
 
 }  // namespace rf
