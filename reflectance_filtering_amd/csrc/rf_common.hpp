@@ -93,8 +93,8 @@ enum DebugOption {
     kDbgGfS1MinWgs,        // guided filter: workgroups a stage-1 launch should at least have (0 = chosen by the library)
     kDbgJbfLookahead1,     // joint bilateral: grey asm loop with the gathers one column step ahead (round-4 form)
     kDbgGfS1LegacyStrips,  // guided filter: stage-1 strips with a halo of exactly r columns on either side (rounds 1-5)
-    kDbgGfNoExact,         // guided filter: every row takes the sequential row walk (no exact-row stage 2)
     kDbgGfExactAllFlagged, // guided filter, exact-row form: treat every row as failing the test (exercises the list path)
+    kDbgGfExact,           // guided filter: exact-row stage 2 (off by default: measured slower, profiles/r06_gf_exact.md)
     kDbgCount
 };
 int debug_get(int id);

@@ -613,7 +613,6 @@ __global__ __launch_bounds__(stage1_threads(SCN))
                     xmn_a[sc] = min(min(xmn_a[sc], (__float_as_uint(a0) << 1) - 2u),
                                     min((__float_as_uint(a1) << 1) - 2u, (__float_as_uint(a2) << 1) - 2u));
                     xmn_b[sc] = min(xmn_b[sc], (__float_as_uint(bt) << 1) - 2u);
-#ifndef RF_X_NOF
                     double d[4];
 #pragma unroll
                     for (int p = 0; p < 4; p++) {
@@ -630,11 +629,9 @@ __global__ __launch_bounds__(stage1_threads(SCN))
                         double *xr = xo.xf + (((size_t)blockIdx.z * ab_groups + sc) * h + y) * 4 * xo.nb;
                         xr[(lane & 3) * xo.nb + (x >> 4)] = dsel;
                     }
-#endif
                 }
             }
         }
-#ifndef RF_X_NOSTAT
         if (EXACT) {
             // the half-wave's statistics: five butterfly steps over packed 16-bit fields (maximum of
             // the largest, maximum of the inverted smallest), lanes 0 and 32 store
@@ -657,7 +654,6 @@ __global__ __launch_bounds__(stage1_threads(SCN))
                              wave * 2 + (lane >> 5)] = make_uint2(wa, wb);
             }
         }
-#endif
         RF_S1_STAMP(5);
         add_row(y - radius, RowOut{});
         RF_S1_STAMP(6);
@@ -1297,10 +1293,12 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
     // Exact rows (rf_gf_fused.hpp): rows whose alpha/beta pass the exactness test need no row walk -
     // stage 1 leaves block sums and per-row statistics, the rows that fail are listed and walked, the
     // column walk starts its chains from the block sums.  Needs a width that is a multiple of 16 and
-    // room for the statistics; debug option "gf_no_exact" keeps the row walk for every row.
+    // room for the statistics.  OFF unless the debug option "gf_exact" is set: bit-identical, measured
+    // slower than the row walk (profiles/r06_gf_exact.md); compiled for the radii of gf_exact_radius.
     const size_t exact_bytes = gf_exact_extra(np, h, w);
     const bool exact =
-        fused && !chained && !keep_gs && w % 16 == 0 && h <= kGfExactMaxH && !debug_get(kDbgGfNoExact) &&
+        fused && !chained && !keep_gs && gf_exact_radius(radius) && w % 16 == 0 && h <= kGfExactMaxH &&
+        debug_get(kDbgGfExact) &&
         !debug_get(kDbgGfS1LegacyStrips) &&
         workspace_bytes - header >= per_img_fused + cmp_bytes + exact_bytes;
     const size_t per_img_used = (fused ? per_img_fused : per_img) + (keep_gs ? gs_bytes : 0) +

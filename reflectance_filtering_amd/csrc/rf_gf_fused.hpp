@@ -499,8 +499,12 @@ __device__ __forceinline__ unsigned gf_chain_tag1(unsigned seed, unsigned j, uns
 //  same kernel fetched 41 instead of 29 B/px at the C5 shard - profiles/r04_c5_traffic.md - so the
 //  experiment is compiled apart, and only for the reference's two radii, kGfChainedRadii.)
 constexpr bool gf_chained_radius(int r) { return r == 45 || r == 52; }
+// (EXACT - the exact-row start of the chains - is a template parameter for the same reason: compiled
+//  into the one kernel, its registers and loads cost the row-walk form 3.6 % alone and 4 ms of the C5
+//  step under two streams, profiles/r06_gf_exact.md; compiled for the same two radii.)
+constexpr bool gf_exact_radius(int r) { return gf_chained_radius(r); }
 
-template <int R, bool CHAINED = false>
+template <int R, bool CHAINED = false, bool EXACT = false>
 __global__ __launch_bounds__(128, (R <= 64 ? 2 : 1)) void gf_colwalk_kernel(
     const float *__restrict__ ab, const double *__restrict__ states,
     const uint8_t *__restrict__ guide, uint8_t *__restrict__ dst, int h, int w, int nb,
@@ -523,7 +527,7 @@ __global__ __launch_bounds__(128, (R <= 64 ? 2 : 1)) void gf_colwalk_kernel(
     __shared__ double sumx[64];
     __shared__ int turn;  // next sub-tile whose column phase may run
     __shared__ int ticket;
-    __shared__ unsigned xmask[CHAINED ? 1 : kGfExactMaxH / 32];  // exact rows: the image's flagged rows
+    __shared__ unsigned xmask[EXACT ? kGfExactMaxH / 32 : 1];  // exact rows: the image's flagged rows
 
     constexpr bool chained = CHAINED;
     const int lane = threadIdx.x & 63;
@@ -534,7 +538,8 @@ __global__ __launch_bounds__(128, (R <= 64 ? 2 : 1)) void gf_colwalk_kernel(
         if (chained)
             ticket = (int)atomicAdd(&xc.sync[blockIdx.x & 7], 1u);
     }
-    if (!chained && xr.on) {
+    static_assert(!(CHAINED && EXACT), "one or the other");
+    if constexpr (EXACT) {
         // (the work item is known from blockIdx alone in this form: see below)
         const int per_xcd_ = (n_pairs + 7) >> 3, q_ = (int)(blockIdx.x >> 3);
         const int pair_ = min((int)(blockIdx.x & 7) * per_xcd_ + q_ / spx, n_pairs - 1);
@@ -588,9 +593,11 @@ __global__ __launch_bounds__(128, (R <= 64 ? 2 : 1)) void gf_colwalk_kernel(
     const char *abgb = reinterpret_cast<const char *>(abg);
     // start of the lane's row chain: the stored state at column 16 b (row-walk form), or - chained -
     // the sum at column 16 b - 1: for block 0 the head sums, else what block b - 1 published
+    // (row-walk form: [plane][nb][h], the layout rf_gf_u8 passes as `lay` for it; exact rows: `lay`)
     const double *Ps = chained ? xc.head + ((size_t)img * np + 4 * s_ch + min(cp, 3)) * h
-                               : stg + (size_t)min(cp, 3) * lay.sp + (size_t)b * lay.sb;
-    const bool exact = !chained && xr.on != 0;
+                       : EXACT ? stg + (size_t)min(cp, 3) * lay.sp + (size_t)b * lay.sb
+                               : stg + ((size_t)min(cp, 3) * nb + b) * h;
+    constexpr bool exact = EXACT;
     // (an interior block's 2q + 1 sums are consecutive doubles: fetched 16 bytes at a time)
     const bool xinner = b - XQ >= 0 && b + XQ < nb && lay.sb == 1;
     // exact rows: the 2q + 1 blocks b - q .. b + q whose sums a chain starts from (reflected like
@@ -640,11 +647,13 @@ __global__ __launch_bounds__(128, (R <= 64 ? 2 : 1)) void gf_colwalk_kernel(
     const int fr = lane >> 2, qd = lane & 3;  // flush role: row of the sub-tile, quad of columns
     float4 pe[NL], pl[NL];
     double pst = 0.0;
-    double pxf[NF];  // exact rows: the prefetched block sums (slot XQ: the state of a flagged row)
+    double pxf[EXACT ? NF : 1];  // exact rows: the prefetched block sums (slot XQ: the state of a flagged row)
     int pxflag = 0;
+    if constexpr (EXACT) {
 #pragma unroll
-    for (int i = 0; i < NF; i++)
-        pxf[i] = 0.0;
+        for (int i = 0; i < NF; i++)
+            pxf[i] = 0.0;
+    }
     uint32_t gpre[3];  // guide bytes of the lane's four output pixels
     double SUM = 0.0;
     double fifo[FL];
@@ -675,7 +684,7 @@ __global__ __launch_bounds__(128, (R <= 64 ? 2 : 1)) void gf_colwalk_kernel(
         }
         if (chain && !take) {
             const int row = L.rowtab[slot][cl];
-            if (exact) {
+            if constexpr (exact) {
                 pxflag = (int)((xmask[row >> 5] >> (row & 31)) & 1u);
                 const double *pr = Ps + (size_t)row * lay.sr;
                 if (xinner) {
@@ -693,7 +702,7 @@ __global__ __launch_bounds__(128, (R <= 64 ? 2 : 1)) void gf_colwalk_kernel(
                         pxf[i] = pr[xkb[i]];
                 }
             } else {
-                pst = Ps[(size_t)row * lay.sr];
+                pst = Ps[row];
             }
         }
     };
@@ -826,10 +835,12 @@ __global__ __launch_bounds__(128, (R <= 64 ? 2 : 1)) void gf_colwalk_kernel(
             }
         }
         double s = take ? take_sums(j) : pst;
-        double xfc[NF];
+        double xfc[EXACT ? NF : 1];
+        if constexpr (EXACT) {
 #pragma unroll
-        for (int i = 0; i < NF; i++)
-            xfc[i] = pxf[i];
+            for (int i = 0; i < NF; i++)
+                xfc[i] = pxf[i];
+        }
         const int xflg = pxflag;
         RF_STAMP(1);  // wait for the operands (and every older store)
         store_pending();
@@ -850,7 +861,7 @@ __global__ __launch_bounds__(128, (R <= 64 ? 2 : 1)) void gf_colwalk_kernel(
 #pragma unroll
             for (int c = 1; c < kSB; c++)
                 d[c] = (double)L.u.st.E[lane][c] - (double)L.u.st.L[lane][c];
-            if (exact) {
+            if constexpr (exact) {
                 // the window sum at column 16 b from block sums, every intermediate a sum over a
                 // subset of that window: prefix of block b + q, the 2q blocks in front of it, the
                 // suffix of block b - q - 1
@@ -1049,14 +1060,23 @@ void gf_fused_launch(const GfFusedArgs &a)
         }
         return;
     }
+    const int streaming = (size_t)a.m * np * a.h * a.w * sizeof(float) > ((size_t)256 << 20) ? 1 : 0;
     if (!(a.exp_skip & 2))
         hipLaunchKernelGGL((gf_rowstate_kernel<R>), dim3((unsigned)(a.m * a.src_cn * row_blocks)),
                            dim3(256), 0, a.stream, a.ab, a.states, a.h, a.w, row_blocks, np, a.colour,
-                           np, a.nb,
-                           (size_t)a.m * np * a.h * a.w * sizeof(float) > ((size_t)256 << 20) ? 1 : 0,
-                           a.lay, a.xr);
-    if (!(a.exp_skip & 4))
-        hipLaunchKernelGGL((gf_colwalk_kernel<R>), dim3(8u * (unsigned)((pairs + 7) / 8) * a.src_cn),
+                           np, a.nb, streaming, a.lay, a.xr);
+    if (a.exp_skip & 4)
+        return;
+    if constexpr (gf_exact_radius(R)) {
+        if (a.xr.on) {
+            hipLaunchKernelGGL((gf_colwalk_kernel<R, false, true>),
+                               dim3(8u * (unsigned)((pairs + 7) / 8) * a.src_cn), dim3(128), 0, a.stream,
+                               a.ab, a.states, a.guide, a.dst, a.h, a.w, a.nb, pairs, a.src_cn, a.colour,
+                               GfChain{nullptr, nullptr, nullptr}, a.compact, a.lay, a.xr);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((gf_colwalk_kernel<R>), dim3(8u * (unsigned)((pairs + 7) / 8) * a.src_cn),
                        dim3(128), 0, a.stream, a.ab, a.states, a.guide, a.dst, a.h, a.w, a.nb, pairs,
                        a.src_cn, a.colour, GfChain{nullptr, nullptr, nullptr}, a.compact, a.lay, a.xr);
 }
