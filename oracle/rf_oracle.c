@@ -597,6 +597,101 @@ static void rfo_box_mean_census(const float *src, float *dst, int h, int w, int 
         g_rfo_census[i] += c[i];
 }
 
+/*
+ * Exact rows (test infrastructure for the GPU's debug option "gf_exact",
+ * reflectance_filtering_amd/csrc/rf_gf_fused.hpp).  For `rows` independent rows of w floats
+ * (w a multiple of 16, w >= 16), per row:
+ *   pass[y]    the sufficient test as the GPU evaluates it on one plane: mx16 = bits of the largest
+ *              magnitude >> 15, mn16 = (smallest non-zero magnitude's (bits << 1) - 2) >> 16; passes
+ *              if mx16 == 0 or max(mx16 >> 8, 1) - max(mn16 >> 8, 1) <= 29 - ceil(log2 ks)
+ *   rounded[y] operations of RowSum<float,double>'s chain (rfo_box_mean's row pass) that rounded
+ *   equal[y]   1 if the row sum at every column 16 b, rebuilt the GPU's way - the sums of the aligned
+ *              16-column blocks as a xor-butterfly over their 16 values, then prefix of block b + q
+ *              (its sum minus the values behind column 16 b + r), blocks b + q - 1 .. b - q, suffix of
+ *              block b - q - 1, block indices reflected like columns - is the chain's double
+ * The claim under test: pass => rounded == 0 and equal == 1.
+ */
+void rfo_exact_rows_check(const float *src, int rows, int w, int r, int *pass, int *rounded, int *equal)
+{
+    int ks = 2 * r + 1, ew = w + ks - 1, nb = w / 16, q = r / 16, c0 = r % 16;
+    int lim = 29;
+    while ((1 << (29 - lim)) < ks)
+        lim--;
+    float *ext = (float *)malloc(sizeof(float) * ew);
+    double *D = (double *)malloc(sizeof(double) * w);
+    double *F = (double *)malloc(sizeof(double) * nb);
+    for (int y = 0; y < rows; y++) {
+        const float *S0 = src + (size_t)y * w;
+        unsigned bmax = 0, tmin = 0xffffffffu;
+        for (int x = 0; x < w; x++) {
+            unsigned u;
+            memcpy(&u, &S0[x], 4);
+            unsigned mag = u & 0x7fffffffu, t = (u << 1) - 2u;
+            if (mag > bmax)
+                bmax = mag;
+            if (t < tmin)
+                tmin = t;
+        }
+        {
+            int mx16 = (int)(bmax >> 15), mn16 = (int)(tmin >> 16);
+            int e1 = mx16 >> 8, e0 = mn16 >> 8;
+            if (e1 < 1)
+                e1 = 1;
+            if (e0 < 1)
+                e0 = 1;
+            pass[y] = (mx16 == 0) || (e1 - e0 <= lim);
+        }
+        for (int x = 0; x < ew; x++)
+            ext[x] = S0[rfo_border_interpolate(x - r, w, RFO_BORDER_REFLECT)];
+        int bad = 0;
+        double s = 0;
+        for (int i = 0; i < ks; i++) {
+            double t = s + (double)ext[i];
+            bad += rfo_add_rounded(s, (double)ext[i], t);
+            s = t;
+        }
+        D[0] = s;
+        for (int i = 0; i < w - 1; i++) {
+            double a = (double)ext[i + ks], b = (double)ext[i];
+            double d = a - b;
+            bad += rfo_add_rounded(a, -b, d);
+            double t = s + d;
+            bad += rfo_add_rounded(s, d, t);
+            s = t;
+            D[i + 1] = s;
+        }
+        rounded[y] = bad;
+        for (int k = 0; k < nb; k++) {
+            double v[16];
+            for (int i = 0; i < 16; i++)
+                v[i] = (double)S0[16 * k + i];
+            for (int m = 1; m < 16; m <<= 1) {
+                double n[16];
+                for (int i = 0; i < 16; i++)
+                    n[i] = v[i] + v[i ^ m];
+                memcpy(v, n, sizeof(v));
+            }
+            F[k] = v[0];
+        }
+        int eq = 1;
+        for (int b = 0; b < nb; b++) {
+            double se = F[rfo_border_interpolate(b + q, nb, RFO_BORDER_REFLECT)];
+            for (int c = 1; c <= 15 - c0; c++)
+                se -= (double)S0[rfo_border_interpolate(16 * b + c + r, w, RFO_BORDER_REFLECT)];
+            for (int k = b + q - 1; k >= b - q; k--)
+                se += F[rfo_border_interpolate(k, nb, RFO_BORDER_REFLECT)];
+            for (int c = 1; c <= c0; c++)
+                se += (double)S0[rfo_border_interpolate(16 * b + c - 1 - r, w, RFO_BORDER_REFLECT)];
+            if (memcmp(&se, &D[16 * b], sizeof(double)) != 0)
+                eq = 0;
+        }
+        equal[y] = eq;
+    }
+    free(F);
+    free(D);
+    free(ext);
+}
+
 /* RFO_VAR_GF_FLOAT_BOXSUM: the same two running sums held in float (RowSum<float,float>,
  * ColumnSum<float,float>: out = s * (float)scale) */
 static void rfo_box_mean_float_sums(const float *src, float *dst, int h, int w, int r)

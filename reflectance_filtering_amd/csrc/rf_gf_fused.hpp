@@ -157,9 +157,9 @@ __device__ __forceinline__ void wave_lds_fence()
 // multiple of 16 (slot = step mod F, static because the loop body is one period of F steps, fully
 // unrolled).  The stream is prefixed with PAD dummy steps so that every chunk of 16 steps is an
 // aligned run of 16 source columns.  A workgroup walks its rows alone from end to end, so the time
-// of the kernel is the time of a chunk: two chunks of loads are in flight (buffers A and B
-// alternate by chunk), and a full chunk forms its 16 operand differences before the chain of
-// dependent adds (one LDS round trip per chunk, not per step).
+// of the kernel is the time of a chunk: up to four chunks of loads are in flight (a ring of buffers,
+// the buffer of every chunk static), and a full chunk forms its 16 operand differences before the
+// chain of dependent adds (one LDS round trip per chunk, not per step).
 // ------------------------------------------------------------------------------------------
 template <int R>
 __global__ __launch_bounds__(256) void gf_rowstate_kernel(const float *__restrict__ planes,
@@ -176,8 +176,13 @@ __global__ __launch_bounds__(256) void gf_rowstate_kernel(const float *__restric
     constexpr int F = (KS + 15) & ~15;
     constexpr int NCH = F / 16;
     constexpr int PAD = (16 - R % 16) % 16;  // step t <-> extended index i = t - PAD, column i - R
-    constexpr int NPER = (NCH & 1) ? 2 : 1;  // periods per loop body: the buffers swap roles from
-                                             // one period to the next when NCH is odd
+    // chunks of loads in flight per workgroup (the kernel is bound by the latency of its loads: with
+    // two, 64 KB per CU are in flight - 4.75 TB/s; registers are free up to 256 at two waves per SIMD),
+    // and periods per loop body: the body covers a whole number of turns of the buffer ring so that
+    // every chunk's buffer is static
+    constexpr int NBUF = (NCH % 2 == 0) ? 4 : (NCH % 3 == 0) ? 3 : 2;
+    constexpr int NPER = (NCH % NBUF == 0) ? 1 : 2;
+    static_assert((NPER * NCH) % NBUF == 0, "the loop body is whole turns of the buffer ring");
     static_assert(KS + PAD <= 2 * F, "the window fills within the two peeled periods");
     const int ng = np / 4;                     // plane groups (src channels) per image
     const int grp = blockIdx.x / row_blocks;   // plane group across the chunk of images
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(256) void gf_rowstate_kernel(const float *__restric
     for (int k = 0; k < 4; k++)
         srow[k] = (uint32_t)slot_row((tid + 256 * k) >> 4) * (uint32_t)w;
 
-    float4 preA[4], preB[4];
+    float4 pre[NBUF][4];
     // (a chunk away from both ends of the row needs no border arithmetic; pixel offsets fit 32
     //  bits - the host admits images below 2^28 pixels here - so a load is SGPR base + byte offset)
     auto fetch = [&](int t0, float4(&buf)[4]) __attribute__((always_inline)) {
@@ -255,8 +260,8 @@ __global__ __launch_bounds__(256) void gf_rowstate_kernel(const float *__restric
             tE[3][r_][cc] = buf[k].w;
         }
         __syncthreads();
-        if (t0 + 32 < total)
-            fetch(t0 + 32, buf);
+        if (t0 + 16 * NBUF < total)
+            fetch(t0 + 16 * NBUF, buf);
         if (PER == 2 && KS >= 16 && t0 + 16 <= total) {
             // full chunk in the steady state: the 16 operands first (16-byte LDS reads), the
             // differences against the FIFO (every value that leaves during the chunk entered in
@@ -308,29 +313,28 @@ __global__ __launch_bounds__(256) void gf_rowstate_kernel(const float *__restric
             }
         }
     };
-    // one period of NCH chunks starting at step t0; PARITY = parity of its first chunk (buffer A
-    // serves the even chunks of the row, B the odd ones)
-    auto period = [&](auto per_c, auto parity_c, int t0) __attribute__((always_inline)) {
-        constexpr int PARITY = decltype(parity_c)::value;
+    // one period of NCH chunks starting at step t0; FIRST = buffer of its first chunk (chunk n of the
+    // row uses buffer n mod NBUF)
+    auto period = [&](auto per_c, auto first_c, int t0) __attribute__((always_inline)) {
+        constexpr int FIRST = decltype(first_c)::value;
         static_for<0, NCH>([&](auto k) __attribute__((always_inline)) {
             constexpr int K = decltype(k)::value;
-            if constexpr (((K + PARITY) & 1) == 0)
-                chunk(per_c, k, t0 + 16 * K, preA);
-            else
-                chunk(per_c, k, t0 + 16 * K, preB);
+            chunk(per_c, k, t0 + 16 * K, pre[(FIRST + K) % NBUF]);
         });
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
-    fetch(0, preA);
-    fetch(16, preB);
+    static_for<0, NBUF>([&](auto k) __attribute__((always_inline)) {
+        constexpr int K = decltype(k)::value;
+        fetch(16 * K, pre[K]);
+    });
     period(I0{}, I0{}, 0);
-    period(I1{}, std::integral_constant<int, NCH & 1>{}, F);
+    period(I1{}, std::integral_constant<int, NCH % NBUF>{}, F);
     for (int t0 = 2 * F; t0 < total; t0 += NPER * F) {
-        period(I2{}, I0{}, t0);  // 2 NCH chunks precede: even parity again
+        period(I2{}, std::integral_constant<int, (2 * NCH) % NBUF>{}, t0);
         if constexpr (NPER == 2)
-            period(I2{}, I1{}, t0 + F);
+            period(I2{}, std::integral_constant<int, (3 * NCH) % NBUF>{}, t0 + F);
     }
 }
 

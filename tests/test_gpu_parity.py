@@ -1088,7 +1088,10 @@ def test_gf_switches_keep_the_bytes(env, radius, eps):
                  {"gf_chained": 1, "gf_no_compact": 1, "gf_force_two_streams": 1},
                  {"gf_stagger": 1}, {"gf_stagger": 1, "gf_parts": 4, "gf_s1_cap": 2},
                  {"gf_stagger": 1, "gf_force_two_streams": 1, "gf_parts": 6, "gf_s1_min_wgs": 64},
-                 {"gf_s1_cap": 3, "gf_s1_min_wgs": 4096}):
+                 {"gf_s1_cap": 3, "gf_s1_min_wgs": 4096},
+                 # round 6: the rounds-1-5 strip geometry; the exact-row stage 2 (this width is not a
+                 # multiple of 16: it must fall back to the row walk by itself)
+                 {"gf_s1_legacy_strips": 1}, {"gf_exact": 1}):
         with rf._ffi.debug_options(**opts):
             got = rf.ops.guided_filter_u8(g, s, radius, eps, iterations=3)
         assert torch.equal(got, want), opts
@@ -1096,6 +1099,65 @@ def test_gf_switches_keep_the_bytes(env, radius, eps):
     want1 = rf.ops.guided_filter_u8(g, one, radius, eps)
     with rf._ffi.debug_options(gf_chained=1):
         assert torch.equal(rf.ops.guided_filter_u8(g, one, radius, eps), want1)
+
+
+@pytest.mark.parametrize("radius,eps", [(45, 3.0), (52, 7.0)])
+def test_gf_exact_rows_against_oracle(env, radius, eps):
+    """The exact-row stage 2 (debug option gf_exact, rf_gf_fused.hpp): rows whose alpha/beta pass the
+    exactness test take no row walk - stage 1 leaves block sums, the column walk starts its chains
+    from them - and must give the ORACLE's bytes: widths that are multiples of 16 (narrower than one
+    window, one strip, several strips), grey / colour / 1-channel src in one batch, three passes;
+    and again with every row forced through the list path (gf_exact_all_flagged)."""
+    from tests import synth
+    rf, co, torch = env
+    for (h, w), n in (((70, 96), 3), ((130, 256), 3), ((97, 1040), 2)):
+        guides = np.stack([synth.flat_guide_u8(h, w, seed=radius + i, cells=14) for i in range(n)])
+        srcs = np.stack([synth.reflectance_like_u8(h, w, seed=100 + i) if i % 2 == 0 else
+                         synth.scene_u8(h, w, seed=100 + i) for i in range(n)])
+        g, s = torch.from_numpy(guides).cuda(), torch.from_numpy(srcs).cuda()
+        want = rf.ops.guided_filter_u8(g, s, radius, eps, iterations=3)
+        for i in range(min(n, 2)):
+            ref = srcs[i]
+            for _ in range(3):
+                ref = co.guided_filter(guides[i], ref, radius, eps)
+            assert np.array_equal(want[i].cpu().numpy(), ref), (h, w, i)
+        for opts in ({"gf_exact": 1}, {"gf_exact": 1, "gf_exact_all_flagged": 1},
+                     {"gf_exact": 1, "gf_one_stream": 1}, {"gf_exact": 1, "gf_no_compact": 1}):
+            with rf._ffi.debug_options(**opts):
+                got = rf.ops.guided_filter_u8(g, s, radius, eps, iterations=3)
+            assert torch.equal(got, want), (h, w, opts)
+        one = s[:, :, :, :1].contiguous()
+        want1 = rf.ops.guided_filter_u8(g, one, radius, eps, iterations=2)
+        with rf._ffi.debug_options(gf_exact=1):
+            assert torch.equal(rf.ops.guided_filter_u8(g, one, radius, eps, iterations=2), want1)
+
+
+def test_gf_exact_rows_adversarial(env):
+    """Rows that FAIL the exactness test must come out of the sequential row walk: (i) a noise guide
+    with a tiny eps (alpha / beta spanning far more than 2^22 within a row), (ii) an image whose
+    upper half is that noise and whose lower half is a flat guide with a smooth src (rows that pass
+    and rows that fail in one image, block boundaries in between), (iii) an all-zero src (alpha and
+    beta exactly 0: the all-zero rows pass).  Every case against the oracle."""
+    from tests import synth
+    rf, co, torch = env
+    h, w, radius = 200, 256, 45
+    rng = np.random.default_rng(77)
+    noise_g = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    noise_s = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    flat_g = synth.flat_guide_u8(h, w, seed=3, cells=9)
+    smooth = synth.reflectance_like_u8(h, w, seed=4)
+    mixed_g, mixed_s = flat_g.copy(), smooth.copy()
+    mixed_g[:h // 2], mixed_s[:h // 2] = noise_g[:h // 2], noise_s[:h // 2]
+    zeros = np.zeros_like(smooth)
+    cases = ((noise_g, noise_s, 1e-3), (mixed_g, mixed_s, 1e-3), (mixed_g, mixed_s, 3.0),
+             (flat_g, zeros, 3.0), (noise_g, smooth, 1e-6))
+    for k, (gd, sr, eps) in enumerate(cases):
+        g = torch.from_numpy(gd[None].copy()).cuda()
+        s = torch.from_numpy(sr[None].copy()).cuda()
+        with rf._ffi.debug_options(gf_exact=1):
+            got = rf.ops.guided_filter_u8(g, s, radius, eps, iterations=2)[0].cpu().numpy()
+        want = co.guided_filter(gd, co.guided_filter(gd, sr, radius, eps), radius, eps)
+        assert np.array_equal(got, want), k
 
 
 def test_gf_radius_beyond_the_8bit_kernels(env):

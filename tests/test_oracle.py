@@ -258,3 +258,54 @@ def test_box_census_counts_rounded_operations():
     L.rfo_census(0, buf)
     assert np.array_equal(out, co.box_mean_f32(plane, 3))
     assert buf[1] == 1 and buf[3] > 0 and buf[8] == 11        # one row rounds, and fails the test
+
+
+def test_exact_rows_sufficient_test_implies_exact_chain():
+    """The proof obligation of the GPU's exact-row stage 2 (debug option gf_exact; DESIGN.md 3.2,
+    rf_gf_fused.hpp) as a property test, no GPU: over 10^5 random rows - smooth, alpha-like with zero
+    crossings, huge dynamic range, denormals, zeros, signs, rows built to sit exactly on the
+    limit - WHENEVER a row passes the sufficient test as the GPU evaluates it, not one operation of
+    RowSum<float,double>'s chain rounds, and the row sum rebuilt from the sums of aligned 16-column
+    blocks (any order of exact additions) is the chain's double at every 16th column.  Rows that
+    fail the test may or may not round: the test is sufficient, not necessary - but some of the
+    failing rows must round, or the instrument could not tell."""
+    import ctypes
+    L = co.lib()
+    fn = L.rfo_exact_rows_check
+    i32p, f32p = ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_float)
+    fn.argtypes = [f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, i32p, i32p, i32p]
+    fn.restype = None
+    rng = np.random.default_rng(2024)
+    total = passed = failed_and_rounded = 0
+    for w, r, rows in ((256, 45, 30000), (96, 45, 20000), (320, 52, 20000), (64, 7, 15000),
+                       (128, 96, 10000), (48, 16, 5000)):
+        kind = rng.integers(0, 8, rows)
+        x = rng.standard_normal((rows, w)).astype(np.float32)
+        scale = np.exp2(rng.integers(-30, 30, (rows, 1))).astype(np.float32)
+        wide = np.exp2(rng.integers(-60, 20, (rows, w)).astype(np.float64)).astype(np.float32)
+        plane = x * scale                                            # kind 0, 1: one magnitude per row
+        plane = np.where(kind[:, None] == 2, x * wide, plane)        # huge dynamic range inside a row
+        plane = np.where(kind[:, None] == 3, np.cumsum(x, 1).astype(np.float32) * np.float32(1e-3), plane)
+        den = (rng.integers(1, 1 << 20, (rows, w)).astype(np.float64) * 2.0 ** -149).astype(np.float32)
+        plane = np.where(kind[:, None] == 4, den * np.sign(x), plane)            # denormals
+        plane = np.where((kind[:, None] == 5) & (rng.random((rows, w)) < 0.7), np.float32(0), plane)
+        # kind 6: integers times one power of two plus ONE tiny value: right at / just past the limit
+        ints = rng.integers(-(1 << 12), 1 << 12, (rows, w)).astype(np.float32)
+        edge = ints * scale
+        tiny = (scale[:, 0] * np.exp2(rng.integers(-40, -8, rows)).astype(np.float32))
+        edge[np.arange(rows), rng.integers(0, w, rows)] = tiny
+        plane = np.where(kind[:, None] == 6, edge, plane)
+        plane = np.where(kind[:, None] == 7, ints, plane)                        # exact integers
+        plane = np.ascontiguousarray(plane, dtype=np.float32)
+        ok = np.zeros(rows, np.int32)
+        bad = np.zeros(rows, np.int32)
+        eq = np.zeros(rows, np.int32)
+        fn(plane.ctypes.data_as(f32p), rows, w, r, ok.ctypes.data_as(i32p), bad.ctypes.data_as(i32p),
+           eq.ctypes.data_as(i32p))
+        sel = ok != 0
+        assert not bad[sel].any(), (w, r, "a row that passes the test rounds")
+        assert eq[sel].all(), (w, r, "block sums differ from the chain on a row that passes")
+        total += rows
+        passed += int(sel.sum())
+        failed_and_rounded += int((bad[~sel] != 0).sum())
+    assert total >= 100000 and passed > total // 4 and failed_and_rounded > 100
