@@ -8,7 +8,10 @@
  *
  *   "gf_two_kernel"      guided filter: row-sum / column-sum kernel pair for every radius (the
  *                        default fuses stage 2 for every radius 1..96); identical bytes
- *   "jbf_compiler_loop"  joint bilateral: compiler-scheduled tap loop; identical bytes
+ *   "jbf_compiler_loop"  joint bilateral: compiler-scheduled tap loop; identical bytes.  (This switch,
+ *                        "jbf_lookahead1" and "jbf_stage_only" act on the 64x64-tile kernel, radius <= 52;
+ *                        the row-band kernel of radius 53..72 has one tap loop and ignores them - its
+ *                        independent check is RF_JBF_FORCE_GENERIC, tests/test_gpu_parity.py)
  *   "jbf_tile64_only"    joint bilateral: no strip tiles at the image remainder; identical bytes
  *   "jbf_tune"           joint bilateral: kernel-variant override 1..7 (tools/jbf_tune.py)
  *   "jbf_f32_untiled"    float joint bilateral: one-thread-per-pixel kernel; identical values
@@ -49,6 +52,14 @@
  *                        whatever fits); identical bytes
  *   "gf_s1_min_wgs"      guided filter: workgroups a stage-1 launch should at least have (chooses the
  *                        rows per segment; 0 = chosen by the library); identical bytes
+ *   "gf_s1_legacy_strips"  guided filter: stage-1 strips with a halo of exactly r columns on either side
+ *                        (rounds 1-5; the default aligns halo and width to 16 columns and takes a whole
+ *                        wave of halo where that costs no strip); identical bytes
+ *   "gf_exact"           guided filter, radius 45 / 52, width a multiple of 16: exact-row stage 2 - rows
+ *                        whose alpha / beta pass an exactness test take no sequential row walk (block sums
+ *                        from stage 1, the rest listed and walked); identical bytes, measured slower
+ *                        (profiles/r06_gf_exact.md), off by default
+ *   "gf_exact_all_flagged"  ... with every row treated as failing the test (exercises the list path)
  */
 #ifndef REFLECTANCE_FILTERING_DEBUG_H
 #define REFLECTANCE_FILTERING_DEBUG_H

@@ -1504,8 +1504,19 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
         const uint8_t *s0 = (it == 0 ? src : (const uint8_t *)dst) + (size_t)P.i0 * npx * src_cn;
         const dim3 ga3(strips3, ceil_div(h, seg_rows3), m), ga1(strips1, ceil_div(h, seg_rows1), m);
         const GfExactOut xo = {P.rows, P.xstat, nb, xslots};
+        // (the occupancy cap's dynamic-LDS pad can take a workgroup beyond the 64 KB a launch may use
+        //  without asking: ask)
+#define RF_GF_S1_ATTR(K, PAD)                                                                      \
+    do {                                                                                           \
+        if ((PAD) > 0)                                                                             \
+            (void)hipFuncSetAttribute((const void *)(K), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)(PAD));                                                 \
+    } while (0)
 #define RF_GF_STAGE1(MODE, EX)                                                                     \
     do {                                                                                           \
+        RF_GF_S1_ATTR((gf_stage1_kernel<3, 3, MODE, EX>), pad3);                                   \
+        RF_GF_S1_ATTR((gf_stage1_kernel<1, 1, MODE, EX>), pad1);                                   \
+        RF_GF_S1_ATTR((gf_stage1_kernel<1, 3, MODE, EX>), pad1);                                   \
         if (src_cn == 3) {                                                                         \
             hipLaunchKernelGGL((gf_stage1_kernel<3, 3, MODE, EX>), ga3, dim3(stage1_threads(3)), pad3, \
                                st, g0, s0, ab, h, w, radius, eps_f, eps_small, seg_rows3, colour,  \
@@ -1535,6 +1546,7 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
         else
             RF_GF_STAGE1(kS1Reuse, false);
 #undef RF_GF_STAGE1
+#undef RF_GF_S1_ATTR
     };
     auto part_stage2 = [&](const Part &P, int it) {
         hipStream_t st = P.st;

@@ -17,8 +17,8 @@
 //                      LDS out-of-range probe fails, and by the tuning harness.
 //   jbf_generic_kernel untiled, any radius, global-memory gathers (fallback + cross-check).
 //   jbf_f32_kernel     the CV_32F variant (rf_jbf_f32), untiled.
-// Parameter tables (colour LUT, tap tables): one device arena per parameter set, uploaded
-// asynchronously on the caller's stream from a pinned host image (get_tables / ensure_tables_on).
+// Parameter tables (colour LUT, tap tables): one device arena per parameter set, uploaded once when
+// the set is first seen (get_tables); entries a captured graph points into are pinned.
 // Shared pieces: jbf_tap_loop (the software-pipelined tap loop, compiler-scheduled VALU) and
 // jbf_tap_loop_grey4 (its hand-interleaved form for grey tiles; J1 = single-channel joint whose
 // pre-scaled texels make v_sad_u32 produce the gather address).
@@ -82,22 +82,21 @@ struct CaptureRelax {
     }
 };
 
-// Owns the arrays of one cache entry: ONE device arena and its pinned host image (the upload is a
-// single asynchronous copy on the stream of whichever call needs the tables first - stream-ordered,
-// no host synchronisation, capturable: SURVEY.md 8(b) "asynchronous on the passed stream").
+// Owns the arrays of one cache entry: ONE device arena, uploaded once when the entry is built - on a
+// stream of its own, waited for there, before the entry is published (the one host wait of a
+// parameter set's first use, tens of microseconds; every later call only enqueues kernels).  The
+// caller's stream may be capturing meanwhile: nothing of the upload enters its graph.
 // rf_jbf_u8 keeps a reference for the duration of the call, so an eviction (or rf_shutdown) on
 // another thread cannot free tables that a call has looked up but not launched yet; the last
 // reference frees them on their own device (hipFree waits for the work queued there).  A graph that
-// captured a call keeps using the entry's arrays: it stays valid while the entry is in the cache
-// (64 parameter sets per process, oldest evicted first).
+// captured a call bakes in pointers into the arena: an entry that was ever looked up on a capturing
+// stream is PINNED - never evicted, freed by rf_shutdown only (destroy such graphs
+// before rf_shutdown).
 struct JbfTableOwner {
     int device = 0;
     void *d_arena = nullptr;
-    void *h_arena = nullptr;  // pinned; a captured upload re-reads it on every replay
     size_t bytes = 0;
-    hipEvent_t uploaded_ev = nullptr;     // recorded behind the first non-captured upload
-    bool ev_recorded = false;             // (under g_mu)
-    std::atomic<bool> resident{false};    // that upload is known to have completed
+    std::atomic<bool> pinned{false};  // referenced by a captured graph
     ~JbfTableOwner()
     {
         int cur = 0;
@@ -105,10 +104,6 @@ struct JbfTableOwner {
                               hipSetDevice(device) == hipSuccess;
         if (d_arena)
             (void)hipFree(d_arena);
-        if (h_arena)
-            (void)hipHostFree(h_arena);
-        if (uploaded_ev)
-            (void)hipEventDestroy(uploaded_ev);
         if (switched)
             (void)hipSetDevice(cur);
     }
@@ -159,32 +154,12 @@ struct TablesHold {
     }
 };
 
-// Makes the tables of entry t usable by work enqueued on `stream` after this call.  Until an upload
-// is known to have completed, every call enqueues its own copy of the (identical) bytes on its own
-// stream in front of its kernels: calls on different streams need no cross-stream dependency, a
-// capturing stream gets the copy as a node of its graph, and nothing waits on the host.
-int ensure_tables_on(const JbfTables &t, hipStream_t stream)
+// The entry is about to be used by work enqueued on `stream`: if that stream is capturing, the graph
+// will hold pointers into the entry's arena for as long as it lives - pin the entry.
+void note_use_on(const JbfTables &t, hipStream_t stream)
 {
-    JbfTableOwner *o = static_cast<JbfTableOwner *>(t.keep.get());
-    if (o->resident.load(std::memory_order_acquire))
-        return RF_OK;
-    {
-        std::lock_guard<std::mutex> lock(g_mu);
-        if (o->ev_recorded && hipEventQuery(o->uploaded_ev) == hipSuccess) {
-            o->resident.store(true, std::memory_order_release);
-            return RF_OK;
-        }
-        (void)hipGetLastError();  // hipErrorNotReady is not an error of this call
-    }
-    RF_HIP_CHECK(hipMemcpyAsync(o->d_arena, o->h_arena, o->bytes, hipMemcpyHostToDevice, stream));
-    if (!stream_is_capturing(stream)) {
-        std::lock_guard<std::mutex> lock(g_mu);
-        if (!o->ev_recorded) {
-            RF_HIP_CHECK(hipEventRecord(o->uploaded_ev, stream));
-            o->ev_recorded = true;
-        }
-    }
-    return RF_OK;
+    if (stream_is_capturing(stream))
+        static_cast<JbfTableOwner *>(t.keep.get())->pinned.store(true, std::memory_order_relaxed);
 }
 
 // Host-side parameter tables, computed in double exactly like jointBilateralFilter_8u does.
@@ -203,8 +178,10 @@ int get_tables(int radius, int joint_cn, double sigma_color, double sigma_space,
                 break;
             }
     }
-    if (out->keep)
-        return ensure_tables_on(*out, stream);
+    if (out->keep) {
+        note_use_on(*out, stream);
+        return RF_OK;
+    }
     JbfTables t;
     t.device = dev;
     t.radius = radius;
@@ -261,14 +238,23 @@ int get_tables(int radius, int joint_cn, double sigma_color, double sigma_space,
     owner->bytes = total;
     t.keep = owner;
     {
-        CaptureRelax relax;  // (the caller's stream may be capturing: see CaptureRelax)
+        // allocation, upload on a private stream and the wait for it: "unsafe" calls while the
+        // caller's stream may be capturing - admitted for this thread by CaptureRelax; the tables
+        // are resident before anybody can find the entry
+        std::vector<char> image(total, 0);
+        for (int k = 0; k < 6; k++)
+            std::memcpy(image.data() + off[k], from[k], part[k]);
+        CaptureRelax relax;
+        hipStream_t ps = nullptr;
+        RF_HIP_CHECK(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
+        struct StreamGuard {
+            hipStream_t s;
+            ~StreamGuard() { (void)hipStreamDestroy(s); }
+        } guard{ps};
         RF_HIP_CHECK(hipMalloc(&owner->d_arena, total));
-        RF_HIP_CHECK(hipHostMalloc(&owner->h_arena, total, hipHostMallocDefault));
-        RF_HIP_CHECK(hipEventCreateWithFlags(&owner->uploaded_ev, hipEventDisableTiming));
+        RF_HIP_CHECK(hipMemcpyAsync(owner->d_arena, image.data(), total, hipMemcpyHostToDevice, ps));
+        RF_HIP_CHECK(hipStreamSynchronize(ps));
     }
-    std::memset(owner->h_arena, 0, total);
-    for (int k = 0; k < 6; k++)
-        std::memcpy(static_cast<char *>(owner->h_arena) + off[k], from[k], part[k]);
     char *db = static_cast<char *>(owner->d_arena);
     t.d_swsym = reinterpret_cast<float *>(db + off[0]);
     t.d_lut = reinterpret_cast<float *>(db + off[1]);
@@ -290,23 +276,33 @@ int get_tables(int radius, int joint_cn, double sigma_color, double sigma_space,
             }
         if (!found) {
             // bounded cache (parameter sweeps must not accumulate device memory): drop the oldest
-            // entry, of this device if there is one; its arrays are freed when the last call using
-            // them returns
+            // entry that no captured graph refers to, of this device if there is one; its arrays are
+            // freed when the last call using them returns.  Pinned entries stay: a cache of nothing
+            // but pinned entries grows.
             if (g_tables.size() >= 64) {
-                size_t victim = 0;
-                for (size_t i = 0; i < g_tables.size(); i++)
+                size_t victim = g_tables.size();
+                for (size_t i = 0; i < g_tables.size(); i++) {
+                    if (static_cast<JbfTableOwner *>(g_tables[i].keep.get())->pinned.load(
+                            std::memory_order_relaxed))
+                        continue;
+                    if (victim == g_tables.size())
+                        victim = i;
                     if (g_tables[i].device == dev) {
                         victim = i;
                         break;
                     }
-                g_retired.push_back(std::move(g_tables[victim].keep));
-                g_tables.erase(g_tables.begin() + victim);
+                }
+                if (victim != g_tables.size()) {
+                    g_retired.push_back(std::move(g_tables[victim].keep));
+                    g_tables.erase(g_tables.begin() + victim);
+                }
             }
             g_tables.push_back(t);
         }
     }
     *out = t;
-    return ensure_tables_on(*out, stream);
+    note_use_on(*out, stream);
+    return RF_OK;
 }
 
 // Packs up to 3 interleaved bytes into the low bytes of a dword (byte 3 = 0), so that

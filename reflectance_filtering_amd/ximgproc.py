@@ -31,7 +31,6 @@ def jointBilateralFilter(joint, src, d, sigmaColor, sigmaSpace, dst=None,
                          borderType=_ffi.BORDER_DEFAULT):
     """cv2.ximgproc.jointBilateralFilter(joint, src, d, sigmaColor, sigmaSpace[, dst[, borderType]])
     for uint8 or float32 images (both of the same depth) with 1 or 3 channels each."""
-    torch = _ffi.require_gpu()
     # OpenCV's own special case (opencv_contrib joint_bilateral_filter.cpp: `if (joint.empty() ||
     # src.data == joint.data) { bilateralFilter(src, dst, d, sigmaColor, sigmaSpace, borderType); return; }`):
     # one buffer passed as both images (or no joint) is filtered by cv::bilateralFilter.  Its 8-bit
@@ -40,9 +39,18 @@ def jointBilateralFilter(joint, src, d, sigmaColor, sigmaSpace, dst=None,
     # 3-channel path) multiply by `1.f / wsum`.  [recalled, unverified like the rest of the OpenCV
     # arithmetic: DESIGN.md 4.]  The reference never gets here - it reads two files into two buffers
     # (/root/reference/filter_reflectance.py:84-85) - but a caller passing the same array twice does.
+    # Detected like OpenCV does, by the data pointer (equal CONTENT in two buffers is the joint filter
+    # there as well).  For float32 images that shortcut lands in cv::bilateralFilter's float path - a
+    # different operator (its own quantised colour table and scaling), which this package does not
+    # implement: refused rather than answered with the joint filter's arithmetic.
     same_buffer = joint is None or joint is src or (
         isinstance(joint, np.ndarray) and isinstance(src, np.ndarray) and joint.shape == src.shape
         and joint.strides == src.strides and joint.ctypes.data == src.ctypes.data)
+    if same_buffer and np.asarray(src).dtype == np.float32:
+        raise ValueError("jointBilateralFilter: one float32 buffer as both joint and src is "
+                         "cv::bilateralFilter's float path in OpenCV, which is not implemented here; "
+                         "pass a copy as joint for the joint filter's arithmetic")
+    torch = _ffi.require_gpu()
     if joint is None:
         joint = src
     if np.asarray(joint).shape[:2] != np.asarray(src).shape[:2]:

@@ -173,6 +173,31 @@ def test_jbf_wide_diameter_with_any_sigma_and_border(env, d, ss, border):
         assert np.array_equal(got, want), (h, w)
 
 
+@pytest.mark.parametrize("sigma_space", [36.0, 40.0, 47.0])
+def test_jbf_wide_radius_against_the_untiled_kernel(env, sigma_space):
+    """Radius 54 / 60 / 70 (the row-band kernel, which has a single tap loop and no test switches of
+    its own) against the one-thread-per-pixel kernel (RF_JBF_FORCE_GENERIC) - an independent code path
+    on the same device - with a colour src (three passes per row band), a grey src and a
+    single-channel joint, and against the oracle for the colour case."""
+    from tests import synth
+    rf, co, torch = env
+    h, w = 150, 210
+    joint = synth.scene_u8(h, w, seed=int(sigma_space))
+    colour = synth.scene_u8(h, w, seed=int(sigma_space) + 1)
+    grey = synth.reflectance_like_u8(h, w, seed=int(sigma_space) + 2)
+    j, c, g = _dev(torch, joint, colour, grey)
+    for src in (c, g):
+        tiled = rf.ops.joint_bilateral_u8(j, src, -1, 15.0, sigma_space)
+        plain = rf.ops.joint_bilateral_u8(j, src, -1, 15.0, sigma_space, flags=rf._ffi.JBF_FORCE_GENERIC)
+        assert torch.equal(tiled, plain)
+    j1 = j[..., :1].contiguous()
+    assert torch.equal(rf.ops.joint_bilateral_u8(j1, g, -1, 15.0, sigma_space),
+                       rf.ops.joint_bilateral_u8(j1, g, -1, 15.0, sigma_space,
+                                                 flags=rf._ffi.JBF_FORCE_GENERIC))
+    want = co.joint_bilateral_filter(joint, colour, -1, 15.0, sigma_space)
+    assert np.array_equal(rf.ops.joint_bilateral_u8(j, c, -1, 15.0, sigma_space)[0].cpu().numpy(), want)
+
+
 def test_jbf_same_buffer_takes_opencvs_bilateral_filter_route(env):
     """cv2.ximgproc.jointBilateralFilter(a, a, ...) - one buffer as joint and src, or no joint - is
     routed by OpenCV to cv::bilateralFilter: for a 1-channel image the last step is a true division
@@ -807,10 +832,11 @@ def test_captured_call_with_cnn_and_raw_entry_point_rules(env):
 def test_jbf_first_use_of_a_parameter_set_inside_a_capture(env):
     """asynchronous on the passed stream, no hidden synchronisation.  A (sigma_color,
     sigma_space) pair the process has never seen is used for the first time INSIDE a graph capture
-    (default, global capture mode): its tables are allocated under a relaxed capture mode and their
-    upload is a node of the graph; the replay gives the oracle's bytes, a second replay after the
-    inputs changed the new bytes, and an eager call on another stream right after the capture (the
-    tables are not resident before the graph first runs) is right as well."""
+    (default, global capture mode): its tables are allocated and uploaded under a relaxed capture mode
+    on a stream of the library's own (nothing but kernels enters the graph); the replay gives the
+    oracle's bytes, a second replay after the inputs changed the new bytes, an eager call on another
+    stream right after the capture is right as well - and the entry the graph points into is PINNED:
+    seventy more parameter sets (the cache holds 64) do not evict it, the graph still replays right."""
     from tests import synth
     rf, co, torch = env
     h, w = 90, 140
@@ -840,6 +866,15 @@ def test_jbf_first_use_of_a_parameter_set_inside_a_capture(env):
     assert np.array_equal(out[0].cpu().numpy(), want)
     src2 = synth.reflectance_like_u8(h, w, seed=33)
     s.copy_(torch.from_numpy(src2[None]).cuda())
+    graph.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(out[0].cpu().numpy(), co.joint_bilateral_filter(joint, src2, -1, sc, ss))
+    # (round 6) 70 other parameter sets go through the 64-entry cache - eager calls, which also free
+    # whatever was retired: the captured entry must have stayed
+    for k in range(70):
+        rf.ops.joint_bilateral_u8(tiny, tiny.clone(), -1, 41.0 + k / 64.0, 2.0)
+    torch.cuda.synchronize()
+    out.zero_()
     graph.replay()
     torch.cuda.synchronize()
     assert np.array_equal(out[0].cpu().numpy(), co.joint_bilateral_filter(joint, src2, -1, sc, ss))
@@ -1088,7 +1123,7 @@ def test_gf_switches_keep_the_bytes(env, radius, eps):
                  {"gf_chained": 1, "gf_no_compact": 1, "gf_force_two_streams": 1},
                  {"gf_stagger": 1}, {"gf_stagger": 1, "gf_parts": 4, "gf_s1_cap": 2},
                  {"gf_stagger": 1, "gf_force_two_streams": 1, "gf_parts": 6, "gf_s1_min_wgs": 64},
-                 {"gf_s1_cap": 3, "gf_s1_min_wgs": 4096},
+                 {"gf_s1_cap": 3, "gf_s1_min_wgs": 4096}, {"gf_s1_cap": 1}, {"gf_s1_cap": 2},
                  # round 6: the rounds-1-5 strip geometry; the exact-row stage 2 (this width is not a
                  # multiple of 16: it must fall back to the row walk by itself)
                  {"gf_s1_legacy_strips": 1}, {"gf_exact": 1}):

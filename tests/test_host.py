@@ -307,3 +307,15 @@ def test_batch_pipeline_orders_overlaps_and_propagates_errors(tmp_path):
         batch.pipeline(items, load, bad, step=3)
     with pytest.raises(ZeroDivisionError):
         batch.pipeline(items, lambda i: 1 // 0, compute, step=3)
+
+
+def test_ximgproc_refuses_the_float_same_buffer_shortcut():
+    """OpenCV sends jointBilateralFilter(a, a) to cv::bilateralFilter; for 8-bit images that is
+    mirrored, for float32 it would be another operator (not implemented): refused before any GPU
+    work, with a message that says what to do."""
+    from reflectance_filtering_amd import ximgproc
+    a = np.zeros((8, 8, 3), np.float32)
+    with pytest.raises(ValueError, match="bilateralFilter"):
+        ximgproc.jointBilateralFilter(a, a, -1, 0.1, 2.0)
+    with pytest.raises(ValueError, match="bilateralFilter"):
+        ximgproc.jointBilateralFilter(None, a, -1, 0.1, 2.0)
