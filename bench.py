@@ -49,6 +49,9 @@ CONFIGS = {
     "c3": ("chain", 256, 333, 500),
     "c4": ("jbf", 512, 1080, 1920),
     "c5": ("gf3", 128, 2160, 3840),
+    # the reference's published 3x guided chain filters a COLOUR reflectance
+    # (/root/reference/README.md:66): the same guide, a 3-channel colour src, 64 images
+    "c5c": ("gf3c", 64, 2160, 3840),
 }
 
 
@@ -434,18 +437,21 @@ class Workload:
                          % (sc, ss, radius, n, w, h,
                             "3-channel colour image" if getattr(args, "src", "grey") == "colour"
                             else "grey map"))
-        elif kind == "gf3":
+        elif kind in ("gf3", "gf3c"):
             self.guide, self.src = flat_guide(scene), grey
+            if kind == "gf3c":
+                self.src = scene.roll(shifts=(37, 91), dims=(1, 2)).contiguous()
+                del grey
             del scene
-            self.dst = torch.empty_like(grey)
+            self.dst = torch.empty_like(self.src)
             self.ws = rf.ops.gf_workspace(n, h, w, 3, 45, device, torch)
             self.step = lambda: rf.ops.guided_filter_u8(self.guide, self.src, 45, 3.0,
                                                         iterations=3, out=self.dst,
                                                         workspace=self.ws)
             self.bytes_per_px = GF_BYTES_PER_PX_X3
             self.name = ("3x guided filter c=3.0 s=45.0 (radius 45, eps 3), batch %d x %dx%d per "
-                         "GPU, piecewise-constant guide (seeded Voronoi cells of flat colour +-1), grey map as src"
-                         % (n, w, h))
+                         "GPU, piecewise-constant guide (seeded Voronoi cells of flat colour +-1), %s as src"
+                         % (n, w, h, "grey map" if kind == "gf3" else "3-channel colour image"))
         else:  # chain
             self.scene = scene
             del grey
@@ -519,6 +525,24 @@ def committed_traffic(n, h, w):
     except (OSError, ValueError):
         pass
     return None, None
+
+
+def committed_config_traffic(key, batch):
+    """HBM-side bytes per step of a secondary configuration from the newest committed bench line
+    that measured it live at this batch (profiles/rNN_bench.json); (None, reason) without one."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench.json")), reverse=True):
+        try:
+            with open(path) as fh:
+                rec = json.load(fh).get(key) or {}
+        except (OSError, ValueError):
+            continue
+        roof = rec.get("roofline") or {}
+        if rec.get("batch") == batch and roof.get("traffic") and "measured by this run" in str(
+                roof.get("traffic_source", "")):
+            return roof["traffic"], ("profiles/%s (rocprofv3 --pmc child passes of an earlier run of "
+                                     "this configuration; not measured by this run)" % os.path.basename(path))
+    return None, "no committed measurement of this configuration"
 
 
 def being_profiled():
@@ -740,6 +764,10 @@ def run_rank(args):
         wl.step()
     elapsed, kernel_ms = wl.timed_steps(args.steps, world, sharding, stub=stub)
     px_total, t_max = sharding.reduce_job(wl.pixels * args.steps, elapsed, world, device=device)
+    # every rank's own per-step time (events on its launch stream; wall clock in the stub): a slow GPU
+    # must not hide behind the max
+    per_rank_ms = sharding.gather_scalars(kernel_ms if kernel_ms is not None
+                                          else elapsed / args.steps * 1e3, world, device=device)
 
     extras = {}
     clock_mhz = None
@@ -795,9 +823,17 @@ def run_rank(args):
                     source += (" (rocprofv3 --pmc passes of this launch shape; not measured by "
                                "this run)")
         headline_traffic = (traffic, source)
+    # the CPU baseline runs on rank 0 at ANY N ("next to the reference CPU filter ... in the same
+    # run", BASELINE.json): after the final barrier, when the other ranks have left the node's cores
     image0 = None
-    if rank == 0 and not stub and world == 1 and kind == "jbf" and args.cpu_seconds > 0:
-        image0 = (wl.joint[0].cpu().numpy(), wl.src[0].cpu().numpy())
+    if rank == 0 and kind == "jbf" and args.cpu_seconds > 0:
+        if stub:
+            import numpy as np
+            rng = np.random.default_rng(5)
+            image0 = (rng.integers(0, 256, (h, w, 3), dtype=np.uint8),
+                      rng.integers(0, 256, (h, w, 3), dtype=np.uint8))
+        else:
+            image0 = (wl.joint[0].cpu().numpy(), wl.src[0].cpu().numpy())
     if (rank == 0 and not stub and world == 1 and not args.no_extras
             and args.config == "north_star"):
         # driver-timed lines for the other BASELINE configurations (one GPU; not `value`)
@@ -811,7 +847,9 @@ def run_rank(args):
             sys.stderr.write("bench.py: WARNING: only %.1f GiB of device memory free - c5_gf runs at batch "
                              "%d instead of its %d-image shard (\"batch_reduced\": true in the line)\n"
                              % (free_b / 2.0 ** 30, c5_batch, CONFIGS["c5"][1]))
-        for key, cfg, nb in (("c3_chain", "c3", 256), ("c5_gf", "c5", c5_batch)):
+        c5c_batch = CONFIGS["c5c"][1] if free_b >= (64 << 30) else 8
+        for key, cfg, nb in (("c3_chain", "c3", 256), ("c5_gf", "c5", c5_batch),
+                             ("c5_gf_colour", "c5c", c5c_batch)):
             k2, _, h2, w2 = CONFIGS[cfg]
             w2l = Workload(k2, nb, h2, w2, args, torch, rf, device, seed=1234 + 1000 * int(cfg[1]))
             w2l.step()
@@ -824,8 +862,8 @@ def run_rank(args):
                                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                         "algorithmic_bytes_per_px": w2l.bytes_per_px}}
             px_step = w2l.pixels
-            if cfg == "c5":
-                extras[key]["batch_reduced"] = nb != CONFIGS["c5"][1]
+            if cfg in ("c5", "c5c"):
+                extras[key]["batch_reduced"] = nb != CONFIGS[cfg][1]
                 # what the step is made of: its VALU-bound stage 1 alone and its memory-bound row /
                 # column walks alone (timing switches of the library, results discarded): the step is
                 # their SUM minus what the second stream recovers from launch tails - the two classes
@@ -843,8 +881,15 @@ def run_rank(args):
             rf.ops.release_workspaces()
             torch.cuda.empty_cache()
             # memory-side traffic of one step of this configuration, per kernel (two --pmc child
-            # passes; never fatal, skipped when profiled / told not to / out of its time)
-            if args.traffic in ("auto", "live") and (args.traffic == "live" or (
+            # passes; never fatal, skipped when profiled / told not to / out of its time).  The C3
+            # chain's passes went to the colour chain in round 6 (6.3 B/px moved against 6 algorithmic
+            # for three rounds running): its line carries the committed number, labelled.
+            if cfg == "c3":
+                c3t, c3src = committed_config_traffic("c3_chain", nb)
+                extras[key]["roofline"].update({"traffic": c3t, "traffic_source": c3src})
+                if c3t:
+                    extras[key]["roofline"]["traffic_bytes_per_px"] = c3t / px_step
+            elif args.traffic in ("auto", "live") and (args.traffic == "live" or (
                     not being_profiled() and os.environ.get("RF_BENCH_CHILD") != "1")):
                 try:
                     rec, why = live_traffic_config(cfg, nb)
@@ -860,7 +905,7 @@ def run_rank(args):
                         {"traffic": rec["traffic"], "traffic_source": rec["traffic_source"],
                          "traffic_bytes_per_px": rec["traffic"] / px_step,
                          "traffic_kernels": rec["kernels"]})
-                    if k2 == "gf3":   # a step is three passes over every pixel
+                    if k2 in ("gf3", "gf3c"):   # a step is three passes over every pixel
                         extras[key]["roofline"]["traffic_bytes_per_px_per_pass"] = (
                             rec["traffic"] / px_step / 3.0)
                     # the rate the memory side actually runs at (measured bytes over the event-timed
@@ -892,13 +937,15 @@ def run_rank(args):
     out = {
         "metric": {"jbf": "megapixels/sec joint-bilateral sigma_c=20 sigma_s=22 @1080p",
                    "gf3": "megapixels/sec 3x guided filter c=3.0 s=45.0 @3840x2160 (BASELINE C5)",
+                   "gf3c": "megapixels/sec 3x guided filter c=3.0 s=45.0 @3840x2160, colour src",
                    "chain": "megapixels/sec 1x1 CNN + BF(CNN,CNN) @IIW size (BASELINE C3)"}[kind],
         "value": value, "unit": "MP/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": t_max / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if kind != "gf3" else "f64", "data": "synthetic",
+        "dtype": "f32" if kind not in ("gf3", "gf3c") else "f64", "data": "synthetic",
         "config": {"workload": wl.name, "name": args.config, "batch_per_gpu": n, "height": h,
                    "width": w, "sharding": "image batch, contiguous slices, no collective"},
+        "per_rank_ms": per_rank_ms, "ranks_seen": len(per_rank_ms),
     }
     if not stub:
         achieved = launch_px * wl.bytes_per_px / (kernel_ms * 1e-3) / 1e9
@@ -926,11 +973,10 @@ def run_rank(args):
         out["config"]["taps_per_px"] = taps
     out.update(extras)
     if image0 is not None:
-        base = cpu_baseline_opencv(image0[0], image0[1], args.sigma_color, args.sigma_spatial,
-                                   args.cpu_seconds)
+        cpu_s = min(args.cpu_seconds, 0.3) if stub else args.cpu_seconds   # (the stub is a flow test)
+        base = cpu_baseline_opencv(image0[0], image0[1], args.sigma_color, args.sigma_spatial, cpu_s)
         if base is None:
-            base = cpu_baseline(image0[0], image0[1], args.sigma_color, args.sigma_spatial,
-                                args.cpu_seconds)
+            base = cpu_baseline(image0[0], image0[1], args.sigma_color, args.sigma_spatial, cpu_s)
         out["cpu_baseline"] = base
     print(json.dumps(out))
     sys.stdout.flush()

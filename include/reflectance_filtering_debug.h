@@ -79,6 +79,10 @@ int rf_debug_option(const char *name, int value);
  * MHz = 100 * out2[0] / out2[1]. */
 int rf_debug_clock_probe(unsigned long long *out2, int micros, void *stream);
 
+/* The toolchain this library was compiled with (`hipcc --version`, first two lines): the inline-asm
+ * hazard audit of tests/test_cabi.py holds for the machine code of that compiler. */
+const char *rf_debug_build_info(void);
+
 #ifdef __cplusplus
 }
 #endif

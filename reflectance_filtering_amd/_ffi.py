@@ -31,7 +31,7 @@ EXPORTS = ("rf_version", "rf_last_error", "rf_shutdown", "rf_jbf_u8", "rf_gf_wor
            "rf_gf_f32_workspace_bytes", "rf_gf_f32")
 
 # include/reflectance_filtering_debug.h: test / benchmark switches, not part of the boundary
-DEBUG_EXPORTS = ("rf_debug_option", "rf_debug_clock_probe")
+DEBUG_EXPORTS = ("rf_debug_option", "rf_debug_clock_probe", "rf_debug_build_info")
 # switches that leave work out (wrong results, timing experiments only); all others keep the bytes
 RESULT_CHANGING_OPTIONS = ("jbf_stage_only", "gf_exp_skip")
 
@@ -96,6 +96,8 @@ def load_library():
         lib.rf_debug_option.restype = ci
         lib.rf_debug_clock_probe.argtypes = [vp, ci, vp]
         lib.rf_debug_clock_probe.restype = ci
+        lib.rf_debug_build_info.argtypes = []
+        lib.rf_debug_build_info.restype = ctypes.c_char_p
         # RF_DEBUG_OPTIONS="name=value,...": preset the test / benchmark switches of
         # include/reflectance_filtering_debug.h for a whole process (timing experiments only).
         # Every preset is announced on stderr - loudly for the switches that change results.

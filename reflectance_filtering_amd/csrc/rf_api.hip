@@ -91,6 +91,13 @@ extern "C" int rf_version(void) { return RF_VERSION | 0x40000000; }
 extern "C" int rf_version(void) { return RF_VERSION; }
 #endif
 
+#ifndef RF_TOOLCHAIN
+#define RF_TOOLCHAIN "unknown toolchain"
+#endif
+// The hand-written asm loops keep LDS / scalar reads in flight across code the compiler writes;
+// tests/test_cabi.py audits the machine code of THIS build - and prints what built it.
+extern "C" const char *rf_debug_build_info(void) { return RF_TOOLCHAIN; }
+
 extern "C" const char *rf_last_error(void) { return rf::last_error_buf(); }
 
 extern "C" int rf_shutdown(void)

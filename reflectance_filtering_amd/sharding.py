@@ -66,3 +66,17 @@ def reduce_job(local_units, local_seconds, world_size, device=None):
     dist.all_reduce(units, op=dist.ReduceOp.SUM)
     dist.all_reduce(secs, op=dist.ReduceOp.MAX)
     return float(units.item()), float(secs.item())
+
+
+def gather_scalars(local_value, world_size, device=None):
+    """Every rank's value of one per-rank measurement, in rank order, on every rank (a slow GPU must
+    be visible behind the job's max: bench.py's `per_rank_ms`)."""
+    if world_size == 1:
+        return [float(local_value)]
+    import torch
+    import torch.distributed as dist
+    dev = device if device is not None and dist.get_backend() != "gloo" else "cpu"
+    mine = torch.tensor([float(local_value)], dtype=torch.float64, device=dev)
+    out = [torch.zeros_like(mine) for _ in range(world_size)]
+    dist.all_gather(out, mine)
+    return [float(t.item()) for t in out]

@@ -77,6 +77,23 @@ def test_bench_launches_its_own_ranks_and_sums_their_pixels():
     job_px = 2 * 4 * 8 * 16 * 3                       # ranks x batch x h x w x steps
     assert np.isclose(out["value"] * 1e6 * out["ms_per_step"] * 1e-3 * 3, job_px, rtol=1e-6)
     assert out["ms_per_step"] >= 10.0                 # the stub step sleeps 10 ms
+    # (round 6) the N > 1 line is self-contained: every rank's own time (a slow GPU must not hide
+    # behind the max), how many ranks reported, and the CPU baseline of the same run (rank 0, after
+    # the final barrier)
+    assert out["ranks_seen"] == 2 and len(out["per_rank_ms"]) == 2
+    assert all(ms >= 10.0 for ms in out["per_rank_ms"])
+    assert max(out["per_rank_ms"]) <= out["ms_per_step"] * 1.5
+    base = out["cpu_baseline"]
+    assert base["kind"] in ("port", "reference") and base["value"] > 0 and base["cores"] >= 1
+    assert base["unit"] == "MP/s" and "sample" in base
+
+
+def test_bench_has_the_colour_chain_configuration():
+    """The reference's published 3x guided chain filters a colour reflectance
+    (/root/reference/README.md:66): `c5_gf_colour` of the N = 1 line is this configuration."""
+    assert bench.CONFIGS["c5c"] == ("gf3c", 64, 2160, 3840)
+    t, why = bench.committed_config_traffic("no_such_line", 1)
+    assert t is None and why
 
 
 def test_bench_refuses_a_world_size_mismatch():

@@ -38,6 +38,23 @@ def test_library_exports_every_declared_symbol(built):
     assert exported == set(names) | set(dbg), exported ^ (set(names) | set(dbg))
 
 
+def test_build_records_its_toolchain(built, record_property, capsys):
+    """The machine-code audits below (registers touched while a read is in flight, packed-FMA
+    operand routing) hold for the code ONE compiler wrote: the library says which, the log shows
+    it, and a library built by something else than the hipcc on this machine is named as such."""
+    lib = _ffi.load_library()
+    info = lib.rf_debug_build_info().decode()
+    record_property("toolchain", info)
+    with capsys.disabled():
+        print("\nlibrf_hip.so built with: %s" % info)
+    assert "HIP version" in info and "clang" in info, info
+    hipcc = "/opt/rocm/bin/hipcc"
+    if os.path.exists(hipcc):
+        here = subprocess.check_output([hipcc, "--version"]).decode().splitlines()[:2]
+        assert all(line.replace('"', "").replace("'", "") in info for line in here), (
+            "the library was built with another toolchain than this machine's: %s" % info)
+
+
 def test_code_object_is_gfx950_only(built, tmp_path):
     tool = "/opt/rocm/lib/llvm/bin/llvm-objdump"
     if not os.path.exists(tool):
