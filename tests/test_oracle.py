@@ -309,3 +309,34 @@ def test_exact_rows_sufficient_test_implies_exact_chain():
         passed += int(sel.sum())
         failed_and_rounded += int((bad[~sel] != 0).sum())
     assert total >= 100000 and passed > total // 4 and failed_and_rounded > 100
+
+
+def test_cnn_oracle_against_torch_cpu_conv():
+    """Third-party arithmetic for the CNN forward (a7): torch's own CPU float32 convolution, ReLU,
+    concatenation and sigmoid on the reference's weights and preprocessing
+    (/root/reference/network_definition.prototxt:9-165 spelled with torch.nn.functional) - not
+    Caffe, but a float32 implementation nobody in this repository wrote.  Summation orders differ
+    (BLAS blocking against the oracle's k-ascending FMA chain), so the bound is a few float32 ulps
+    of a value below 1, and the uint8 map may move by one in a few pixels."""
+    torch = pytest.importorskip("torch")
+    F = torch.nn.functional
+    g = np.load(os.path.join(G, "cnn_forward.npz"))
+    wts = torch.from_numpy(g["weights"].astype(np.float32))
+    lut = torch.from_numpy(co.srgb_lut())
+    for key in ("bgr32", "ramp"):
+        bgr = g[key]
+        r, r8 = co.cnn_reflectance(bgr, g["weights"])
+        rgb = torch.from_numpy(np.ascontiguousarray(bgr[:, :, ::-1])).long()
+        x = lut[rgb].permute(2, 0, 1).unsqueeze(0)                      # 1 x 3 x H x W, linear
+        cur = F.relu(F.conv2d(x, wts[:96].reshape(32, 3, 1, 1), wts[96:128]))
+        feats, q = [cur], 128
+        for _ in range(4):
+            cur = F.relu(F.conv2d(cur, wts[q:q + 1024].reshape(32, 32, 1, 1), wts[q + 1024:q + 1056]))
+            q += 1056
+            feats.append(cur)
+        z = F.conv2d(torch.cat(feats, 1), wts[q:q + 160].reshape(1, 160, 1, 1), wts[q + 160:q + 161])
+        rt = torch.sigmoid(z)[0, 0].numpy()
+        assert rt.dtype == np.float32
+        assert np.abs(rt - r).max() < 1e-5, key
+        delta = (rt * 255).astype(np.uint8).astype(int) - r8.astype(int)
+        assert np.abs(delta).max() <= 1 and np.mean(delta != 0) < 0.01
