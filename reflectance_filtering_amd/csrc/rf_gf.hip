@@ -352,8 +352,10 @@ __global__ __launch_bounds__(stage1_threads(SCN))
     const uint8_t *__restrict__ guide, const uint8_t *__restrict__ src, float *__restrict__ ab,
     int h, int w, int radius, float eps_f, int eps_small, int seg_rows,
     const int *__restrict__ colour, float *__restrict__ gs, int ab_groups, int hl, int out_w,
-    const GfExactOut xo)
+    const GfExactOut xo, const uint8_t *__restrict__ src_planar)
 {
+    // src_planar (three-channel kernel, later passes of an iterated call): the src channels as three
+    // planes [img][3][h][w] - what the previous pass's column walk left - instead of interleaved
     static_assert(!EXACT || MODE == kS1Full, "exact rows: plain stage 1 only");
     // hl, out_w: the strip's geometry - its kACW columns are image columns xs - hl .. xs - hl + kACW - 1
     // (xs = strip index x out_w), of which columns hl .. hl + out_w - 1 are its outputs; hl >= radius
@@ -387,12 +389,14 @@ __global__ __launch_bounds__(stage1_threads(SCN))
     // byte offsets of the thread's columns within an image row (guide: 3 bytes per pixel, src: SPX);
     // a row's bytes are then (wave-uniform row pointer) + (32-bit lane offset): no 64-bit vector
     // arithmetic per load
+    const bool planar = SCN == 3 && src_planar != nullptr;
+    const uint8_t *pimg = planar ? src_planar + (size_t)blockIdx.z * npx * 3 : nullptr;
     uint32_t gx3[kACols], gxs[kACols];
 #pragma unroll
     for (int k = 0; k < kACols; k++) {
         const int gx = border_interpolate(xs - hl + tid * kACols + k, w, RF_BORDER_REFLECT);
         gx3[k] = (uint32_t)gx * 3u;
-        gxs[k] = (uint32_t)gx * (uint32_t)SPX;
+        gxs[k] = planar ? (uint32_t)gx : (uint32_t)gx * (uint32_t)SPX;
     }
 
     uint32_t V[kACols][NQ];
@@ -413,8 +417,12 @@ __global__ __launch_bounds__(stage1_threads(SCN))
         const int gy = border_interpolate(yy, h, RF_BORDER_REFLECT);
         const auto rg = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<uint8_t *>(gimg + (size_t)gy * w * 3), 0, w * 3, 0x00020000);
+        // (planar: one descriptor over the three planes' common row offset .. the last plane's row,
+        //  channel sc at byte sc * npx + column; interleaved: the row's w * SPX bytes)
         const auto rp = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<uint8_t *>(simg + (size_t)gy * w * SPX), 0, w * SPX, 0x00020000);
+            const_cast<uint8_t *>(planar ? pimg + (size_t)gy * w : simg + (size_t)gy * w * SPX), 0,
+            planar ? (int)(2 * npx) + w : w * SPX, 0x00020000);
+        const int pstep = planar ? (int)npx : 1;
 #pragma unroll
         for (int k = 0; k < kACols; k++) {
             const uint32_t g01 = __builtin_amdgcn_raw_buffer_load_b16(rg, (int)gx3[k], 0, 0);
@@ -422,7 +430,7 @@ __global__ __launch_bounds__(stage1_threads(SCN))
             int p[SCN];
 #pragma unroll
             for (int sc = 0; sc < SCN; sc++)
-                p[sc] = __builtin_amdgcn_raw_buffer_load_b8(rp, (int)gxs[k] + sc, 0, 0);
+                p[sc] = __builtin_amdgcn_raw_buffer_load_b8(rp, (int)gxs[k], sc * pstep, 0);
             Q::template accumulate<NEG>((int)(g01 & 0xffu), (int)(g01 >> 8), g2, p, V[k]);
         }
     };
@@ -1152,7 +1160,8 @@ extern "C" size_t rf_gf_workspace_bytes(int n, int h, int w, int guide_cn, int s
         per_img = std::max(per_img, rf::gf_per_img_row_walk((size_t)h * w, 4 * src_cn,
                                                             rf::ceil_div(w, rf::kSB), h) +
                                         rf::gf_exact_extra(4 * src_cn, h, w) +
-                                        (((size_t)h * w + 15) & ~(size_t)15));
+                                        (((size_t)h * w + 15) & ~(size_t)15) +
+                                        (src_cn == 3 ? ((3 * (size_t)h * w + 15) & ~(size_t)15) : 0));
     }
     // enough images in flight to fill the chip and to make the tails of the launches small: capped
     // at 1/8 of the device's memory, at most 32 GiB (6 GiB when no device can be asked).  C5 shard
@@ -1290,6 +1299,16 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
          workspace_bytes - header >= per_img_fused + (keep_gs ? gs_bytes : 0) + cmp_want)
             ? cmp_want
             : 0;
+    // Colour images of an iterated call hand their result from pass to pass as three PLANES in the
+    // workspace (round 6): every channel's column walk then stores 4 bytes per lane instead of four
+    // single bytes into the interleaved dst (its vector-memory instructions are what it is short
+    // of), stage 1 of the next pass reads bytes either way; the last pass writes dst as before.
+    const size_t cmp3_want = (3 * npx + 15) & ~(size_t)15;
+    const size_t cmp3_bytes =
+        (cmp_bytes && iterations > 1 && !keep_gs &&
+         workspace_bytes - header >= per_img_fused + cmp_bytes + cmp3_want)
+            ? cmp3_want
+            : 0;
     // Exact rows (rf_gf_fused.hpp): rows whose alpha/beta pass the exactness test need no row walk -
     // stage 1 leaves block sums and per-row statistics, the rows that fail are listed and walked, the
     // column walk starts its chains from the block sums.  Needs a width that is a multiple of 16 and
@@ -1300,9 +1319,9 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
         fused && !chained && !keep_gs && gf_exact_radius(radius) && w % 16 == 0 && h <= kGfExactMaxH &&
         debug_get(kDbgGfExact) &&
         !debug_get(kDbgGfS1LegacyStrips) &&
-        workspace_bytes - header >= per_img_fused + cmp_bytes + exact_bytes;
+        workspace_bytes - header >= per_img_fused + cmp_bytes + cmp3_bytes + exact_bytes;
     const size_t per_img_used = (fused ? per_img_fused : per_img) + (keep_gs ? gs_bytes : 0) +
-                                cmp_bytes + (exact ? exact_bytes : 0);
+                                cmp_bytes + cmp3_bytes + (exact ? exact_bytes : 0);
     int chunk = (int)std::min<size_t>((size_t)n, (workspace_bytes - header) / per_img_used);
     if (chunk > 16383)
         chunk = 16383;
@@ -1363,7 +1382,7 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
         const int *colour;
         double *rows;
         float *ab, *gs;
-        uint8_t *cmp;
+        uint8_t *cmp, *cmp3;
         uint2 *xstat;            // exact rows: statistics, list and its lengths, flag bitmask
         unsigned *rowmask;
         int *xlist, *xcount;
@@ -1409,12 +1428,13 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
         P.cmp = cmp_bytes ? reinterpret_cast<uint8_t *>(P.ab + (size_t)m * np * npx) +
                                 (keep_gs ? (size_t)m * gs_bytes : 0)
                           : nullptr;
+        P.cmp3 = cmp3_bytes ? P.cmp + (size_t)m * cmp_bytes : nullptr;  // [m][3][npx]
         P.xstat = nullptr;
         P.rowmask = nullptr;
         P.xlist = P.xcount = nullptr;
         if (exact) {
             char *xb = reinterpret_cast<char *>(P.ab + (size_t)m * np * npx) +
-                       (keep_gs ? (size_t)m * gs_bytes : 0) + (size_t)m * cmp_bytes;
+                       (keep_gs ? (size_t)m * gs_bytes : 0) + (size_t)m * (cmp_bytes + cmp3_bytes);
             const size_t rows_all = (size_t)m * src_cn * h;
             P.xstat = reinterpret_cast<uint2 *>(xb);
             P.xlist = reinterpret_cast<int *>(P.xstat + rows_all * xslots);
@@ -1520,19 +1540,19 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
         if (src_cn == 3) {                                                                         \
             hipLaunchKernelGGL((gf_stage1_kernel<3, 3, MODE, EX>), ga3, dim3(stage1_threads(3)), pad3, \
                                st, g0, s0, ab, h, w, radius, eps_f, eps_small, seg_rows3, colour,  \
-                               gs, 3, geo3.hl, geo3.out_w, xo);                                    \
+                               gs, 3, geo3.hl, geo3.out_w, xo, it > 0 ? P.cmp3 : nullptr);         \
             if (cmp != nullptr)                                                                    \
                 hipLaunchKernelGGL((gf_stage1_kernel<1, 1, MODE, EX>), ga1, dim3(stage1_threads(1)), \
                                    pad1, st, g0, cmp, ab, h, w, radius, eps_f, eps_small,          \
-                                   seg_rows1, colour, gs, 3, geo1.hl, geo1.out_w, xo);             \
+                                   seg_rows1, colour, gs, 3, geo1.hl, geo1.out_w, xo, nullptr);    \
             else                                                                                   \
                 hipLaunchKernelGGL((gf_stage1_kernel<1, 3, MODE, EX>), ga1, dim3(stage1_threads(1)), \
                                    pad1, st, g0, s0, ab, h, w, radius, eps_f, eps_small,           \
-                                   seg_rows1, colour, gs, 3, geo1.hl, geo1.out_w, xo);             \
+                                   seg_rows1, colour, gs, 3, geo1.hl, geo1.out_w, xo, nullptr);    \
         } else {                                                                                   \
             hipLaunchKernelGGL((gf_stage1_kernel<1, 1, MODE, EX>), ga1, dim3(stage1_threads(1)), pad1, \
                                st, g0, s0, ab, h, w, radius, eps_f, eps_small, seg_rows1, colour,  \
-                               gs, 1, geo1.hl, geo1.out_w, xo);                                    \
+                               gs, 1, geo1.hl, geo1.out_w, xo, nullptr);                           \
         }                                                                                          \
     } while (0)
         if (debug_get(kDbgGfExpSkip) & 1)
@@ -1564,7 +1584,8 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
             }
             const GfFusedArgs fa = {P.ab, P.rows, P.g0, P.d0, m, h, w, nb, src_cn, P.colour, st, P.xc,
                                     debug_get(kDbgGfExpSkip),
-                                    it + 1 < iterations ? P.cmp : nullptr, lay, xr};
+                                    it + 1 < iterations ? P.cmp : nullptr, lay, xr,
+                                    it + 1 < iterations ? P.cmp3 : nullptr};
             fused_launch(fa);
             return;
         }

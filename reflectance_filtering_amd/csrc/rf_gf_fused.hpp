@@ -513,7 +513,8 @@ __global__ __launch_bounds__(128, (R <= 64 ? 2 : 1)) void gf_colwalk_kernel(
     const float *__restrict__ ab, const double *__restrict__ states,
     const uint8_t *__restrict__ guide, uint8_t *__restrict__ dst, int h, int w, int nb,
     int n_pairs, int spx, const int *__restrict__ colour, const GfChain xc,
-    uint8_t *__restrict__ compact, const GfStateLayout lay, const GfExact xr)
+    uint8_t *__restrict__ compact, const GfStateLayout lay, const GfExact xr,
+    uint8_t *__restrict__ compact3)
 {
     using G = WalkGeom<R>;
     constexpr int M = G::M, T = G::T;
@@ -588,6 +589,9 @@ __global__ __launch_bounds__(128, (R <= 64 ? 2 : 1)) void gf_colwalk_kernel(
     uint8_t *dimg = dst + (size_t)img * npx * spx;
     // a grey 3-channel image of an iterated call hands its result on as one byte per pixel
     uint8_t *cimg = (grey3 && compact != nullptr) ? compact + (size_t)img * npx : nullptr;
+    // ... and a colour image as three planes, [img][3][h][w]: this channel's plane
+    if (spx == 3 && !grey3 && compact3 != nullptr)
+        cimg = compact3 + ((size_t)img * 3 + s_ch) * npx;
     // RowSum at output column o = 16 b + cc (cc >= 1):  + ext[o + 2r] - ext[o - 1], ext[i] = S[bi(i - r)]
     // per-lane BYTE offsets of the float4 pixel from the wave-uniform base abg of the channel's
     // plane group ([h][w][4] floats; 32 bits: the host admits images below 2^28 pixels here)
@@ -772,7 +776,7 @@ __global__ __launch_bounds__(128, (R <= 64 ? 2 : 1)) void gf_colwalk_kernel(
         if (fr >= st_tj || y >= h || x >= w)
             return;
         const uint32_t pix = (uint32_t)y * w + x;
-        if (x + 3 < w && (grey3 || spx == 1)) {
+        if (x + 3 < w && (grey3 || spx == 1 || cimg != nullptr)) {
             if (cimg != nullptr) {
                 __builtin_memcpy(cimg + pix, &o4, 4);
             } else if (grey3) {  // every result byte three times: 12 contiguous bytes
@@ -1038,6 +1042,7 @@ struct GfFusedArgs {
     uint8_t *compact;  // not the last pass of an iterated call: grey 3-channel images go here, 1 B per pixel
     GfStateLayout lay;  // where a (plane, block, row) state / block sum sits
     GfExact xr;         // exact rows: flags and list of the rows that take the row walk (on = 0: all do)
+    uint8_t *compact3;  // not the last pass of an iterated call: colour images go here as three planes
 };
 typedef void (*GfFusedLaunch)(const GfFusedArgs &);
 GfFusedLaunch gf_fused_launcher(int radius);  // nullptr outside 1 .. kGfFusedMaxRadius
@@ -1060,7 +1065,8 @@ void gf_fused_launch(const GfFusedArgs &a)
                 hipLaunchKernelGGL((gf_colwalk_kernel<R, true>),
                                    dim3(8u * (unsigned)((a.m + 7) / 8) * a.src_cn * a.nb), dim3(128),
                                    0, a.stream, a.ab, a.states, a.guide, a.dst, a.h, a.w, a.nb, pairs,
-                                   a.src_cn, a.colour, a.chain, a.compact, a.lay, GfExact{nullptr, nullptr, nullptr, 0, 0});
+                                   a.src_cn, a.colour, a.chain, a.compact, a.lay, GfExact{nullptr, nullptr, nullptr, 0, 0},
+                                   a.compact3);
         }
         return;
     }
@@ -1076,13 +1082,14 @@ void gf_fused_launch(const GfFusedArgs &a)
             hipLaunchKernelGGL((gf_colwalk_kernel<R, false, true>),
                                dim3(8u * (unsigned)((pairs + 7) / 8) * a.src_cn), dim3(128), 0, a.stream,
                                a.ab, a.states, a.guide, a.dst, a.h, a.w, a.nb, pairs, a.src_cn, a.colour,
-                               GfChain{nullptr, nullptr, nullptr}, a.compact, a.lay, a.xr);
+                               GfChain{nullptr, nullptr, nullptr}, a.compact, a.lay, a.xr, a.compact3);
             return;
         }
     }
     hipLaunchKernelGGL((gf_colwalk_kernel<R>), dim3(8u * (unsigned)((pairs + 7) / 8) * a.src_cn),
                        dim3(128), 0, a.stream, a.ab, a.states, a.guide, a.dst, a.h, a.w, a.nb, pairs,
-                       a.src_cn, a.colour, GfChain{nullptr, nullptr, nullptr}, a.compact, a.lay, a.xr);
+                       a.src_cn, a.colour, GfChain{nullptr, nullptr, nullptr}, a.compact, a.lay, a.xr,
+                       a.compact3);
 }
 
 }  // namespace rf
