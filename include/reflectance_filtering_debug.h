@@ -60,6 +60,9 @@
  *                        from stage 1, the rest listed and walked); identical bytes, measured slower
  *                        (profiles/r06_gf_exact.md), off by default
  *   "gf_exact_all_flagged"  ... with every row treated as failing the test (exercises the list path)
+ *   "gf_cw_chan_run"     guided filter, colour src, passes of an iterated call that hand their result on as
+ *                        planes: n + 1 = the column walk takes an XCD's (block, channel) items in runs of n
+ *                        blocks per channel (0 = the library's choice, 64; 1 = channel fastest); identical bytes
  */
 #ifndef REFLECTANCE_FILTERING_DEBUG_H
 #define REFLECTANCE_FILTERING_DEBUG_H

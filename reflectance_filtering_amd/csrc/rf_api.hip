@@ -44,7 +44,7 @@ extern "C" int rf_debug_option(const char *name, int value)
                                                       "gf_exp_skip",       "gf_stagger",        "gf_parts",
                                                       "gf_s1_cap",         "gf_s1_min_wgs",
                                                       "jbf_lookahead1",    "gf_s1_legacy_strips",
-                                                      "gf_exact_all_flagged", "gf_exact"};
+                                                      "gf_exact_all_flagged", "gf_cw_chan_run",   "gf_exact"};
     static_assert(sizeof(names) / sizeof(names[0]) == rf::kDbgCount, "one name per DebugOption");
     if (name)
         for (int i = 0; i < rf::kDbgCount; i++)

@@ -94,6 +94,7 @@ enum DebugOption {
     kDbgJbfLookahead1,     // joint bilateral: grey asm loop with the gathers one column step ahead (round-4 form)
     kDbgGfS1LegacyStrips,  // guided filter: stage-1 strips with a halo of exactly r columns on either side (rounds 1-5)
     kDbgGfExactAllFlagged, // guided filter, exact-row form: treat every row as failing the test (exercises the list path)
+    kDbgGfCwChanRun,       // guided filter, colour src, planar passes: n + 1 = runs of n pairs per channel in the column walk's item order (0: the library's 64; 1: channel fastest)
     kDbgGfExact,           // guided filter: exact-row stage 2 (off by default: measured slower, profiles/r06_gf_exact.md)
     kDbgCount
 };

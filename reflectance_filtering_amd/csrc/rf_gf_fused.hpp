@@ -22,6 +22,7 @@
 #pragma once
 #include "rf_common.hpp"
 
+#include <algorithm>
 #include <type_traits>
 
 namespace rf {
@@ -514,7 +515,7 @@ __global__ __launch_bounds__(128, (R <= 64 ? 2 : 1)) void gf_colwalk_kernel(
     const uint8_t *__restrict__ guide, uint8_t *__restrict__ dst, int h, int w, int nb,
     int n_pairs, int spx, const int *__restrict__ colour, const GfChain xc,
     uint8_t *__restrict__ compact, const GfStateLayout lay, const GfExact xr,
-    uint8_t *__restrict__ compact3)
+    uint8_t *__restrict__ compact3, int chan_group)
 {
     using G = WalkGeom<R>;
     constexpr int M = G::M, T = G::T;
@@ -547,8 +548,14 @@ __global__ __launch_bounds__(128, (R <= 64 ? 2 : 1)) void gf_colwalk_kernel(
     if constexpr (EXACT) {
         // (the work item is known from blockIdx alone in this form: see below)
         const int per_xcd_ = (n_pairs + 7) >> 3, q_ = (int)(blockIdx.x >> 3);
-        const int pair_ = min((int)(blockIdx.x & 7) * per_xcd_ + q_ / spx, n_pairs - 1);
-        const unsigned *gm = xr.rowmask + (size_t)((pair_ / nb) * spx + q_ % spx) * xr.mask_words;
+        int pl_ = q_ / spx, ch_ = q_ % spx;
+        if (chan_group > 0) {
+            const int r_ = q_ % (chan_group * spx);
+            ch_ = r_ / chan_group;
+            pl_ = q_ / (chan_group * spx) * chan_group + r_ % chan_group;
+        }
+        const int pair_ = min((int)(blockIdx.x & 7) * per_xcd_ + pl_, n_pairs - 1);
+        const unsigned *gm = xr.rowmask + (size_t)((pair_ / nb) * spx + ch_) * xr.mask_words;
         for (int i = threadIdx.x; i < xr.mask_words; i += 128)
             xmask[i] = gm[i];
     }
@@ -567,10 +574,19 @@ __global__ __launch_bounds__(128, (R <= 64 ? 2 : 1)) void gf_colwalk_kernel(
     } else {
         const int per_xcd = (n_pairs + 7) >> 3;
         const int q = (int)(blockIdx.x >> 3);
-        const int pair = (int)(blockIdx.x & 7) * per_xcd + q / spx;
-        if (q / spx >= per_xcd || pair >= n_pairs)
-            return;
+        // order of an XCD's (pair, channel) items: channel fastest (chan_group = 0: the channels of a
+        // block run side by side and share its guide rows), or runs of chan_group pairs per channel
+        // (a channel's neighbouring blocks stay neighbours in time, as on a grey batch)
+        int pl = q / spx;
         s_ch = q % spx;
+        if (chan_group > 0) {
+            const int r = q % (chan_group * spx);
+            s_ch = r / chan_group;
+            pl = q / (chan_group * spx) * chan_group + r % chan_group;
+        }
+        const int pair = (int)(blockIdx.x & 7) * per_xcd + pl;
+        if (pl >= per_xcd || pair >= n_pairs)
+            return;
         b = pair % nb;
         img = pair / nb;
     }
@@ -1043,6 +1059,7 @@ struct GfFusedArgs {
     GfStateLayout lay;  // where a (plane, block, row) state / block sum sits
     GfExact xr;         // exact rows: flags and list of the rows that take the row walk (on = 0: all do)
     uint8_t *compact3;  // not the last pass of an iterated call: colour images go here as three planes
+    int chan_group;     // column walk: pairs per channel run in an XCD's item order (0: channel fastest)
 };
 typedef void (*GfFusedLaunch)(const GfFusedArgs &);
 GfFusedLaunch gf_fused_launcher(int radius);  // nullptr outside 1 .. kGfFusedMaxRadius
@@ -1066,7 +1083,7 @@ void gf_fused_launch(const GfFusedArgs &a)
                                    dim3(8u * (unsigned)((a.m + 7) / 8) * a.src_cn * a.nb), dim3(128),
                                    0, a.stream, a.ab, a.states, a.guide, a.dst, a.h, a.w, a.nb, pairs,
                                    a.src_cn, a.colour, a.chain, a.compact, a.lay, GfExact{nullptr, nullptr, nullptr, 0, 0},
-                                   a.compact3);
+                                   a.compact3, 0);
         }
         return;
     }
@@ -1077,19 +1094,24 @@ void gf_fused_launch(const GfFusedArgs &a)
                            np, a.nb, streaming, a.lay, a.xr);
     if (a.exp_skip & 4)
         return;
+    // items per XCD: its pairs x channels, rounded up to whole channel runs
+    const int per_xcd = (pairs + 7) / 8;
+    const int cgrp = a.src_cn == 1 ? 0 : std::min(a.chan_group, per_xcd);
+    const unsigned cw_grid =
+        8u * (unsigned)(cgrp > 0 ? (per_xcd + cgrp - 1) / cgrp * cgrp : per_xcd) * a.src_cn;
     if constexpr (gf_exact_radius(R)) {
         if (a.xr.on) {
             hipLaunchKernelGGL((gf_colwalk_kernel<R, false, true>),
-                               dim3(8u * (unsigned)((pairs + 7) / 8) * a.src_cn), dim3(128), 0, a.stream,
+                               dim3(cw_grid), dim3(128), 0, a.stream,
                                a.ab, a.states, a.guide, a.dst, a.h, a.w, a.nb, pairs, a.src_cn, a.colour,
-                               GfChain{nullptr, nullptr, nullptr}, a.compact, a.lay, a.xr, a.compact3);
+                               GfChain{nullptr, nullptr, nullptr}, a.compact, a.lay, a.xr, a.compact3, cgrp);
             return;
         }
     }
-    hipLaunchKernelGGL((gf_colwalk_kernel<R>), dim3(8u * (unsigned)((pairs + 7) / 8) * a.src_cn),
+    hipLaunchKernelGGL((gf_colwalk_kernel<R>), dim3(cw_grid),
                        dim3(128), 0, a.stream, a.ab, a.states, a.guide, a.dst, a.h, a.w, a.nb, pairs,
                        a.src_cn, a.colour, GfChain{nullptr, nullptr, nullptr}, a.compact, a.lay, a.xr,
-                       a.compact3);
+                       a.compact3, cgrp);
 }
 
 }  // namespace rf

@@ -1126,7 +1126,8 @@ def test_gf_switches_keep_the_bytes(env, radius, eps):
                  {"gf_s1_cap": 3, "gf_s1_min_wgs": 4096}, {"gf_s1_cap": 1}, {"gf_s1_cap": 2},
                  # round 6: the rounds-1-5 strip geometry; the exact-row stage 2 (this width is not a
                  # multiple of 16: it must fall back to the row walk by itself)
-                 {"gf_s1_legacy_strips": 1}, {"gf_exact": 1}):
+                 {"gf_s1_legacy_strips": 1}, {"gf_exact": 1}, {"gf_cw_chan_run": 1},
+                 {"gf_cw_chan_run": 4}, {"gf_cw_chan_run": 100000, "gf_one_stream": 1}):
         with rf._ffi.debug_options(**opts):
             got = rf.ops.guided_filter_u8(g, s, radius, eps, iterations=3)
         assert torch.equal(got, want), opts
