@@ -282,6 +282,40 @@ __global__ __launch_bounds__(256) void gf_grey_probe_kernel(const uint8_t *__res
         colour[blockIdx.y] = 1;
 }
 
+// Last pass of a colour image that travelled as planes: planes [img][3][npx] -> dst [img][npx][3].
+// grid: (blocks per image, images); images whose flag colour[img] is 0 (grey: their last pass wrote dst
+// itself) are skipped.  Four pixels per thread: three 4-byte loads, one 12-byte store.
+__global__ __launch_bounds__(256) void gf_interleave3_kernel(const uint8_t *__restrict__ planes,
+                                                             uint8_t *__restrict__ dst, size_t npx,
+                                                             const int *__restrict__ colour)
+{
+    if (colour[blockIdx.y] == 0)
+        return;
+    const uint8_t *p = planes + (size_t)blockIdx.y * npx * 3;
+    uint8_t *d = dst + (size_t)blockIdx.y * npx * 3;
+    const size_t nquads = npx / 4;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nquads;
+         q += (size_t)gridDim.x * blockDim.x) {
+        uint32_t c0, c1, c2;
+        __builtin_memcpy(&c0, p + q * 4, 4);
+        __builtin_memcpy(&c1, p + npx + q * 4, 4);
+        __builtin_memcpy(&c2, p + 2 * npx + q * 4, 4);
+        // bytes out: b0 g0 r0 b1 | g1 r1 b2 g2 | r2 b3 g3 r3   (channel planes c0, c1, c2)
+        const uint32_t o[3] = {
+            (c0 & 0xffu) | ((c1 & 0xffu) << 8) | ((c2 & 0xffu) << 16) | ((c0 & 0xff00u) << 16),
+            ((c1 >> 8) & 0xffu) | (((c2 >> 8) & 0xffu) << 8) | (((c0 >> 16) & 0xffu) << 16) |
+                (((c1 >> 16) & 0xffu) << 24),
+            ((c2 >> 16) & 0xffu) | ((c0 >> 24) << 8) | ((c1 >> 24) << 16) | ((c2 >> 24) << 24)};
+        __builtin_memcpy(d + q * 12, o, 12);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(npx - nquads * 4)) {
+        const size_t i = nquads * 4 + threadIdx.x;
+        d[i * 3 + 0] = p[i];
+        d[i * 3 + 1] = p[npx + i];
+        d[i * 3 + 2] = p[2 * npx + i];
+    }
+}
+
 // grid: (strips, row segments, images).  ab: [img][SPX][h][w][4] float (g<3 alpha, g=3 beta).
 // SCN = src channels computed, SPX = src bytes per pixel (SCN, or 3 with SCN = 1 for a grey
 // 3-channel image whose first channel stands for all three).
@@ -1299,13 +1333,13 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
          workspace_bytes - header >= per_img_fused + (keep_gs ? gs_bytes : 0) + cmp_want)
             ? cmp_want
             : 0;
-    // Colour images of an iterated call hand their result from pass to pass as three PLANES in the
-    // workspace (round 6): every channel's column walk then stores 4 bytes per lane instead of four
-    // single bytes into the interleaved dst (its vector-memory instructions are what it is short
-    // of), stage 1 of the next pass reads bytes either way; the last pass writes dst as before.
+    // Colour images leave every pass as three PLANES in the workspace (round 6): a channel's column
+    // walk then stores 4 bytes per lane instead of four single bytes into the interleaved dst (its
+    // vector-memory instructions are what it is short of), stage 1 of the next pass reads bytes either
+    // way, and a small kernel interleaves the last pass's planes into dst (6 B/px at copy speed).
     const size_t cmp3_want = (3 * npx + 15) & ~(size_t)15;
     const size_t cmp3_bytes =
-        (cmp_bytes && iterations > 1 && !keep_gs &&
+        (cmp_bytes && !keep_gs &&
          workspace_bytes - header >= per_img_fused + cmp_bytes + cmp3_want)
             ? cmp3_want
             : 0;
@@ -1584,19 +1618,22 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
             }
             const GfFusedArgs fa = {P.ab, P.rows, P.g0, P.d0, m, h, w, nb, src_cn, P.colour, st, P.xc,
                                     debug_get(kDbgGfExpSkip),
-                                    it + 1 < iterations ? P.cmp : nullptr, lay, xr,
-                                    it + 1 < iterations ? P.cmp3 : nullptr,
-                                    // colour images: an XCD walks its (pair, channel) items in runs of 64
-                                    // pairs per channel on the passes that hand on planes - a channel's
+                                    it + 1 < iterations ? P.cmp : nullptr, lay, xr, P.cmp3,
+                                    // colour images (which leave the walk as planes): an XCD walks its (pair,
+                                    // channel) items in runs of 64 pairs per channel - a channel's
                                     // neighbouring blocks then stay neighbours in time and find each other's
-                                    // operands in the L2 (81.6 against 82.8 ms per colour chain); the last
-                                    // pass stores single bytes into the interleaved dst, where the three
+                                    // operands in the L2 (81.6 against 82.8 ms per colour chain).  Without
+                                    // the planes (no room in the workspace, "gf_no_compact") the walk
+                                    // stores single bytes into the interleaved dst, where the three
                                     // channels of a block want to run side by side (channel fastest: 0).
                                     // Debug option "gf_cw_chan_run": n + 1 forces runs of n (1: channel fastest)
-                                    it + 1 < iterations && P.cmp3 != nullptr
+                                    P.cmp3 != nullptr
                                         ? (debug_get(kDbgGfCwChanRun) ? debug_get(kDbgGfCwChanRun) - 1 : 64)
                                         : 0};
             fused_launch(fa);
+            if (P.cmp3 != nullptr && it + 1 == iterations && !(debug_get(kDbgGfExpSkip) & 4))
+                hipLaunchKernelGGL(gf_interleave3_kernel, dim3(probe_blocks, m), dim3(256), 0, st, P.cmp3,
+                                   P.d0, npx, P.colour);
             return;
         }
         const int row_blocks = ceil_div(h, kBRows);
