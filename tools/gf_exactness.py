@@ -8,7 +8,7 @@ never rounds is the exact sum, hence order-free.  This tool counts, with a TwoSu
 operation of the oracle's chains (oracle/rf_oracle.c rfo_box_mean_census), how often that is the
 case on the inputs of BASELINE config C5 and on a natural-image guide.
 
-    python tools/gf_exactness.py [--height 2160 --width 3840] [--out profiles/r05_gf_exactness.md]
+    python tools/gf_exactness.py [--height 2160 --width 3840] [--out profiles/r06_gf_exactness.md]
 """
 import argparse
 import ctypes
@@ -68,7 +68,7 @@ def main():
     cases = (("C5: flat (Voronoi) guide, grey src", flat_np, grey_np[:, :, :1].copy()),
              ("C5 guide, colour src", flat_np, colour_src),
              ("natural-image guide (the scene), grey src", scene_np, grey_np[:, :, :1].copy()))
-    lines = ["# r05 - exactness census of the guided filter's stage 2 (box means of alpha / beta)",
+    lines = ["# exactness census of the guided filter's stage 2 (box means of alpha / beta)",
              "",
              "`python tools/gf_exactness.py --height %d --width %d` (CPU; oracle/rf_oracle.c "
              "`rfo_box_mean_census`: the oracle's chains with a TwoSum check on every double "
