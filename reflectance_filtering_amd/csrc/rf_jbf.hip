@@ -11,8 +11,8 @@
 //   jbf_tile64_kernel  default for radius <= 52: one workgroup = 64x64 output tile (32x128,
 //                      16x256 or 128x32 for the image's remainder rows / columns), 1024 threads
 //                      (4 waves/SIMD), LDS-staged texel tile, LUT at the end of LDS.
-//   jbf_wide_kernel    radius 53..72: the same 64x64 outputs in row-band passes of 32 / 16 rows at
-//                      row pitch 208 / 240 (the grey loop; a colour src one pass per channel).
+//   jbf_slab_kernel    radius 53..132: the same 64x64 outputs with the disk's tap rows taken in slabs
+//                      (row pitch 208 .. 336; the grey loop; a colour src one pass per channel).
 //   jbf_tiled2_kernel  64 x TH tiles with 8-byte texels and a clamped/full LUT: used when the
 //                      LDS out-of-range probe fails, and by the tuning harness.
 //   jbf_generic_kernel untiled, any radius, global-memory gathers (fallback + cross-check).
@@ -986,15 +986,22 @@ __device__ __forceinline__ void jbf_tap_loop_grey4(uint32_t lut_lane_addr, uint3
 // the step within the group), the src byte converted when its texel is at hand for the SAD (two steps
 // before use) so that a texel pair is free for re-use after its second SAD: two pairs still suffice.
 // Same instructions per step, same arithmetic and order: identical bytes.
-template <int LUTREP, int TLW, bool J1 = false>
+// SLAB (round 6, jbf_slab_kernel): the loop runs the tap rows i_first .. i_last only - a slab of the disk's
+// rows whose texels are what the LDS tile holds at the moment, tile row of tap row i for the lane's output
+// row = ty + i + row_bias - and ADDS to sum / wsum: slabs taken in increasing i keep every pixel's taps in
+// row-major order, so any radius runs through this loop with the bytes of one pass over the whole disk.
+template <int LUTREP, int TLW, bool J1 = false, bool SLAB = false>
 __device__ __forceinline__ void jbf_tap_loop_grey4_la2(uint32_t lut_lane_addr,
                                                        const float *__restrict__ swsym,
                                                        uint32_t tile_lane_addr,
                                                        const uint32_t (&jc)[kPix], int ty, int radius,
                                                        int r4, int sw_len,
                                                        const int *__restrict__ hwtab,
-                                                       float (&sum)[kPix][1], float (&wsum)[kPix])
+                                                       float (&sum)[kPix][1], float (&wsum)[kPix],
+                                                       int i_first = 0, int i_last = 0, int row_bias = 0)
 {
+    const int i_lo = SLAB ? i_first : -radius, i_hi = SLAB ? i_last : radius;
+    const int bias = SLAB ? row_bias : radius;
     constexpr int Q4 = TLW / 4;
     constexpr int SHIFT = LUTREP == 32 ? 7 : LUTREP == 16 ? 6 : LUTREP == 8 ? 5 : 4;
     static_assert(LUTREP == 32 || LUTREP == 16 || LUTREP == 8 || LUTREP == 4, "LUT replicas");
@@ -1016,7 +1023,7 @@ __device__ __forceinline__ void jbf_tap_loop_grey4_la2(uint32_t lut_lane_addr,
         const int hws = (hw + 1) & ~1;
         const int ai = i < 0 ? -i : i;
         const int c0 = r4 - hws;  // first column, relative to the lane's quad origin
-        const int quad = (i + radius) * TLW + (c0 >> 2);
+        const int quad = (i + bias) * TLW + (c0 >> 2);
         const int phase = (c0 >> 1) & 1;
         ta_out = lane_row0 + (uint32_t)((quad + (phase ? 2 * Q4 : 0)) * 4);
         tb_out = lane_row0 + (uint32_t)((quad + (phase ? 1 : 2 * Q4)) * 4);
@@ -1037,7 +1044,14 @@ __device__ __forceinline__ void jbf_tap_loop_grey4_la2(uint32_t lut_lane_addr,
     float sv[4];         // sv[u]: src value of column u as float
     uint32_t ta, tb, wa_addr;
     int ngroups;
-    row_addr(-radius, 0, ta, tb, wa_addr, ngroups);  // (the top row of the disk: half-width 0)
+    if constexpr (SLAB) {
+        int hw0;
+        const int *hp0 = hwtab + (i_lo + radius);
+        asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(hw0) : "s"(hp0));
+        row_addr(i_lo, __builtin_amdgcn_readfirstlane(hw0), ta, tb, wa_addr, ngroups);
+    } else {
+        row_addr(-radius, 0, ta, tb, wa_addr, ngroups);  // (the top row of the disk: half-width 0)
+    }
     // The half-width of row i + 1 is needed during row i (its last group reads ahead into row i + 1).
     // A load the compiler issues gets its wait - a full one - at the first use, in the middle of a row
     // with four gathers in flight: one pipeline drain per row.  So the value is requested a row early
@@ -1045,7 +1059,7 @@ __device__ __forceinline__ void jbf_tap_loop_grey4_la2(uint32_t lut_lane_addr,
     // full wait in the middle of its step 3 (RF_L2_WAIT_WINDOW), a row at least one group.
     int hw_ahead;
     {
-        const int *hp = hwtab + 1;
+        const int *hp = SLAB ? hwtab + ((i_lo + 1 < i_hi ? i_lo + 1 : i_hi) + radius) : hwtab + 1;
         asm volatile("s_load_dword %0, %1, 0x0" : "=s"(hw_ahead) : "s"(hp));  // (waited for below)
     }
     // prologue: both texel pairs and the weight window of the first group, gathers and src values of
@@ -1189,14 +1203,14 @@ __device__ __forceinline__ void jbf_tap_loop_grey4_la2(uint32_t lut_lane_addr,
         STEP(3, gg[3], gg[1], NB, 0, 0, "s_waitcnt lgkmcnt(0)\n\t", "s_waitcnt lgkmcnt(4)")      \
     }
 #define RF_L2_ROW_LOOP(STEP)                                                                      \
-    for (int i = -radius; i <= radius; i++) {                                                     \
+    for (int i = i_lo; i <= i_hi; i++) {                                                          \
         uint32_t ta_next, tb_next, wa_next;                                                       \
         int ngroups_next;                                                                         \
         asm volatile("" : "+s"(hw_ahead)); /* behind the full waits of the row before */           \
-        row_addr(i < radius ? i + 1 : i, __builtin_amdgcn_readfirstlane(hw_ahead), ta_next,       \
+        row_addr(i < i_hi ? i + 1 : i, __builtin_amdgcn_readfirstlane(hw_ahead), ta_next,         \
                  tb_next, wa_next, ngroups_next);                                                 \
         {                                                                                         \
-            const int *hp_ = hwtab + ((i + 2 < radius ? i + 2 : radius) + radius);                \
+            const int *hp_ = hwtab + ((i + 2 < i_hi ? i + 2 : i_hi) + radius);                    \
             asm volatile("s_load_dword %0, %1, 0x0" : "=s"(hw_ahead) : "s"(hp_));                 \
         }                                                                                         \
         for (int gq = 0; gq < ngroups - 1; gq++) {                                                \
@@ -1842,101 +1856,6 @@ __device__ inline void store_quad_channel(uint8_t *dst, size_t img, int oy, int 
     }
 }
 
-// Radius 53..72 (--sigma_spatial is a free float of the reference's tool,
-// /root/reference/filter_reflectance.py:117-119: sigma 36 -> radius 54, 40 -> 60, 47 -> 70): the 64x64
-// tile with its halo no longer fits the LDS, so a workgroup covers its 64x64 outputs in 64/crows passes
-// of crows rows (32 up to radius 68, 16 beyond), each pass staging (crows + 2r) rows of 4-byte texels
-// {B,G,R joint, ONE src byte} at row pitch 208 (240 for radius 69..72) and running the grey asm tap
-// loop on its first 16*crows threads; the weights come through scalar loads, so the LDS holds only the
-// tile and the LUT.  A 3-channel src whose channels differ takes
-// three such passes per row band, one per channel - the weights are formed three times (78 instead
-// of 44 VALU instructions per column step), which is still an order of magnitude below the
-// one-thread-per-pixel kernel these radii fell to before.  Per-pixel tap order and arithmetic are
-// those of every other form: identical bytes.
-template <int GREP, int TLW>
-__global__ __launch_bounds__(1024) void jbf_wide_kernel(
-    const uint8_t *__restrict__ joint, const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
-    int h, int w, int jcn, int scn, int radius, int border, const float *__restrict__ lut, int nz,
-    const int *__restrict__ hwtab, const float *__restrict__ swsym, int sw_len, int tiles_x,
-    int tiles_per_img, int flags, int crows)
-{
-    constexpr int NT = 1024, Q4 = TLW / 4, QW = 16;
-    static_assert(TLW % 32 == 16, "row pitch keeps the rows of a half-wave on disjoint banks");
-    extern __shared__ __align__(16) unsigned char smem[];
-    int *flag_word = reinterpret_cast<int *>(smem);
-    // (no weight table in LDS: the grey loop takes its weight windows through scalar loads)
-    uint32_t *tile4 = reinterpret_cast<uint32_t *>(smem + 16);
-    const int tid = threadIdx.x;
-    if (tid == 0)
-        *flag_word = 3;
-    const int tile_id = xcd_contiguous_tile((int)blockIdx.x, (int)gridDim.x);
-    const int img_idx = tile_id / tiles_per_img;
-    const int t_in_img = tile_id - img_idx * tiles_per_img;
-    const int tile_y0 = (t_in_img / tiles_x) * 64;
-    const int tile_x0 = (t_in_img % tiles_x) * 64;
-    const size_t img = (size_t)img_idx * h * w;
-    const int r4 = (radius + 3) & ~3;
-    const int tx = tid % QW, ty = tid / QW;
-    // the LUT at the very end of the allocation: gathers past its last entry read 0 (probed)
-    float *lut_g = reinterpret_cast<float *>(smem + kT64Lds - nz * GREP * 4);
-    for (int i = tid; i < nz * GREP; i += NT)
-        lut_g[i] = lut[i / GREP];
-    const int tlh = crows + 2 * radius;
-    const uint32_t lut_lane_addr = lds_addr(lut_g) + (uint32_t)(tid & (GREP - 1)) * 4u;
-    const uint32_t tile_lane_addr = lds_addr(tile4) + (uint32_t)tx * 4u;
-    for (int y0 = tile_y0; y0 < tile_y0 + 64 && y0 < h; y0 += crows) {
-        int all_grey = scn == 1;
-        for (int c = 0; c < scn; c++) {
-            __syncthreads();  // everyone is done with the previous contents of the tile (and flag)
-            int grey = 1;
-            for (int item = tid; item < tlh * Q4; item += NT) {
-                const int ry = item / Q4, k = item - ry * Q4;
-                const int gy = border_interpolate(y0 - radius + ry, h, border);
-                uint32_t jv[4], sv[4];
-                load_tile_quad(joint, src, img, gy, tile_x0 - r4 + 4 * k, w, jcn, scn, border, jv, sv);
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    if (c == 0 && scn == 3)
-                        grey &= (int)(((sv[u] ^ (sv[u] >> 8)) & 0xffffu) == 0u);
-                    tile4[ry * TLW + u * Q4 + k] = jv[u] | (((sv[u] >> (8 * c)) & 0xffu) << 24);
-                }
-            }
-            if (c == 0 && scn == 3) {
-                all_grey = block_all2(grey, 1, flag_word) & 1;  // (barrier inside)
-                __syncthreads();                                // everyone has read the word
-                if (tid == 0)
-                    *flag_word = 3;
-            } else {
-                __syncthreads();
-            }
-            if (tid < QW * crows) {
-                uint32_t jc[kPix];
-#pragma unroll
-                for (int p = 0; p < kPix; p++) {
-                    const int X = 4 * tx + p + r4;
-                    jc[p] = tile4[(ty + radius) * TLW + (X & 3) * Q4 + (X >> 2)] & 0x00ffffffu;
-                }
-                float sum1[kPix][1], wsum[kPix];
-#pragma unroll
-                for (int p = 0; p < kPix; p++) {
-                    sum1[p][0] = 0.f;
-                    wsum[p] = 0.f;
-                }
-                jbf_tap_loop_grey4_la2<GREP, TLW>(lut_lane_addr, swsym, tile_lane_addr, jc, ty,
-                                                  radius, r4, sw_len, hwtab, sum1, wsum);
-                if (scn == 1)
-                    store_quad<1, 1>(dst, img, y0 + ty, tile_x0 + 4 * tx, h, w, sum1, wsum, flags);
-                else if (all_grey)
-                    store_quad<1, 3>(dst, img, y0 + ty, tile_x0 + 4 * tx, h, w, sum1, wsum, flags);
-                else
-                    store_quad_channel(dst, img, y0 + ty, tile_x0 + 4 * tx, h, w, c, sum1, wsum, flags);
-            }
-            if (all_grey)
-                break;
-        }
-    }
-}
-
 // Probe for the "LDS reads beyond the allocation return 0" behaviour the 64x64 kernel relies on.
 __global__ void lds_oob_probe_kernel(uint32_t *out)
 {
@@ -2140,33 +2059,146 @@ int launch_tile64_rows(const JbfTables &t, int nz, int crows, const uint8_t *joi
     return rc;
 }
 
-// Radius 53..72: rows per pass of jbf_wide_kernel at row pitch tlw for a LUT replicated grep times
-// (0: does not fit).  The LDS holds the tile and the LUT (the weights travel through SGPRs).
-int wide_fits(const JbfTables &t, int nz, int grep, int tlw)
+// ------------------------------------------------------------------------------------------
+// Radius 53..132 (--sigma_spatial is a free float of the reference's tool,
+// /root/reference/filter_reflectance.py:117-119: sigma 36 -> radius 54, 47 -> 70, 66 -> 99, 88 -> 132):
+// the 64x64 tile with its halo no longer fits the LDS.  The workgroup covers its 64x64 outputs in bands of
+// `crows` rows (all 64 - every lane busy - wherever that leaves room for a slab of 24 rows) and takes
+// the disk's 2r + 1 tap rows in SLABS of `slab_rows`: the LDS holds the band's rows plus one slab of
+// halo at a time, 4-byte texels {B,G,R joint, ONE src byte}, the accumulators stay in registers from
+// slab to slab (jbf_tap_loop_grey4_la2<.., SLAB>; the weights come through scalar loads, so the LDS
+// holds only tile and LUT), and every pixel's taps still arrive in row-major order - the bytes of
+// the one-pass kernels and of the oracle.  The row pitch (64 outputs + 2 r4 + 8 columns) is bounded
+// by the 8-bit offsets of the loop's ds_read2: 336 texels, r4 <= 132; beyond that the untiled kernel
+// remains.  A 3-channel src whose channels differ takes one pass per channel (the weights are
+// formed three times).  Round 5's row-band kernel (radius 53..72: bands of 32 / 16 / 8 rows with the
+// whole halo staged, i.e. a half to an eighth of the lanes busy) is gone: slabs run 7.3 G taps/s at
+// every radius (0.95 of the radius-33 rate) where the bands ran 6.7 at radius 54, 3.7 at radius 70.
+// ------------------------------------------------------------------------------------------
+template <int GREP, int TLW>
+__global__ __launch_bounds__(1024) void jbf_slab_kernel(
+    const uint8_t *__restrict__ joint, const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
+    int h, int w, int jcn, int scn, int radius, int border, const float *__restrict__ lut, int nz,
+    const int *__restrict__ hwtab, const float *__restrict__ swsym, int sw_len, int tiles_x,
+    int tiles_per_img, int flags, int crows, int slab_rows)
 {
+    constexpr int NT = 1024, Q4 = TLW / 4, QW = 16;
+    static_assert(TLW % 32 == 16, "row pitch keeps the rows of a half-wave on disjoint banks");
+    extern __shared__ __align__(16) unsigned char smem[];
+    int *flag_word = reinterpret_cast<int *>(smem);
+    uint32_t *tile4 = reinterpret_cast<uint32_t *>(smem + 16);
+    const int tid = threadIdx.x;
+    if (tid == 0)
+        *flag_word = 3;
+    const int tile_id = xcd_contiguous_tile((int)blockIdx.x, (int)gridDim.x);
+    const int img_idx = tile_id / tiles_per_img;
+    const int t_in_img = tile_id - img_idx * tiles_per_img;
+    const int tile_y0 = (t_in_img / tiles_x) * 64;
+    const int tile_x0 = (t_in_img % tiles_x) * 64;
+    const size_t img = (size_t)img_idx * h * w;
+    const int r4 = (radius + 3) & ~3;
+    const int tx = tid % QW, ty = tid / QW;
+    float *lut_g = reinterpret_cast<float *>(smem + kT64Lds - nz * GREP * 4);
+    for (int i = tid; i < nz * GREP; i += NT)
+        lut_g[i] = lut[i / GREP];
+    const uint32_t lut_lane_addr = lds_addr(lut_g) + (uint32_t)(tid & (GREP - 1)) * 4u;
+    const uint32_t tile_lane_addr = lds_addr(tile4) + (uint32_t)tx * 4u;
+    const bool active = tid < QW * crows;
+    for (int y0 = tile_y0; y0 < tile_y0 + 64 && y0 < h; y0 += crows) {
+        int all_grey = scn == 1;
+        for (int c = 0; c < scn; c++) {
+            // the lane's four centre pixels (their joint values; border arithmetic as in the tile)
+            uint32_t jc[kPix];
+            float sum1[kPix][1], wsum[kPix];
+            {
+                uint32_t jv[4], sv[4];
+                load_tile_quad(joint, src, img, min(y0 + ty, h - 1), tile_x0 + 4 * tx, w, jcn, scn, border,
+                               jv, sv);
+#pragma unroll
+                for (int p = 0; p < kPix; p++) {
+                    jc[p] = jv[p] & 0x00ffffffu;
+                    sum1[p][0] = 0.f;
+                    wsum[p] = 0.f;
+                }
+            }
+            int grey = 1;
+            for (int i0 = -radius; i0 <= radius; i0 += slab_rows) {
+                const int i1 = min(i0 + slab_rows - 1, radius);
+                const int tlh = crows + (i1 - i0);
+                __syncthreads();  // everyone is done with the previous contents of the tile (and flag)
+                for (int item = tid; item < tlh * Q4; item += NT) {
+                    const int ry = item / Q4, k = item - ry * Q4;
+                    const int gy = border_interpolate(y0 + i0 + ry, h, border);
+                    uint32_t jv[4], sv[4];
+                    load_tile_quad(joint, src, img, gy, tile_x0 - r4 + 4 * k, w, jcn, scn, border, jv, sv);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (c == 0 && scn == 3)
+                            grey &= (int)(((sv[u] ^ (sv[u] >> 8)) & 0xffffu) == 0u);
+                        tile4[ry * TLW + u * Q4 + k] = jv[u] | (((sv[u] >> (8 * c)) & 0xffu) << 24);
+                    }
+                }
+                __syncthreads();
+                if (active)
+                    jbf_tap_loop_grey4_la2<GREP, TLW, false, true>(lut_lane_addr, swsym, tile_lane_addr, jc,
+                                                                   ty, radius, r4, sw_len, hwtab, sum1, wsum,
+                                                                   i0, i1, -i0);
+            }
+            if (c == 0 && scn == 3) {
+                __syncthreads();
+                all_grey = block_all2(grey, 1, flag_word) & 1;  // (barrier inside)
+                __syncthreads();                                // everyone has read the word
+                if (tid == 0)
+                    *flag_word = 3;
+            }
+            if (active) {
+                if (scn == 1)
+                    store_quad<1, 1>(dst, img, y0 + ty, tile_x0 + 4 * tx, h, w, sum1, wsum, flags);
+                else if (all_grey)
+                    store_quad<1, 3>(dst, img, y0 + ty, tile_x0 + 4 * tx, h, w, sum1, wsum, flags);
+                else
+                    store_quad_channel(dst, img, y0 + ty, tile_x0 + 4 * tx, h, w, c, sum1, wsum, flags);
+            }
+            if (all_grey)
+                break;
+        }
+    }
+}
+
+// rows per band and per slab of jbf_slab_kernel at row pitch tlw for a LUT replicated grep times
+// (crows = 0: does not fit): all 64 rows of the tile in one band - every lane busy - as long as a
+// slab is at least 24 rows, else 32, else 16
+void slab_fits(const JbfTables &t, int nz, int grep, int tlw, int *crows, int *slab_rows)
+{
+    *crows = *slab_rows = 0;
     if (2 * t.r4 + 64 + 8 > tlw)
-        return 0;
-    for (int crows = 32; crows >= 8; crows >>= 1)
-        if (16 + (size_t)tlw * (crows + 2 * t.radius) * 4 + (size_t)nz * grep * 4 <= (size_t)kT64Lds)
-            return crows;
-    return 0;
+        return;
+    const long long rows = ((long long)kT64Lds - 16 - (long long)nz * grep * 4) / ((long long)tlw * 4);
+    for (int cr : {64, 32, 16}) {
+        const long long sl = rows - cr + 1;
+        if (sl >= (cr == 16 ? 8 : 24)) {
+            *crows = cr;
+            *slab_rows = (int)std::min<long long>(sl, 2 * t.radius + 1);
+            return;
+        }
+    }
 }
 
 template <int GREP, int TLW>
-int launch_wide(const JbfTables &t, int nz, int crows, const uint8_t *joint, const uint8_t *src,
-                uint8_t *dst, int n, int h, int w, int jcn, int scn, int border, int flags,
-                hipStream_t stream)
+int launch_slab(const JbfTables &t, int nz, int crows, int slab_rows, const uint8_t *joint,
+                const uint8_t *src, uint8_t *dst, int n, int h, int w, int jcn, int scn, int border,
+                int flags, hipStream_t stream)
 {
     const int tiles_x = ceil_div(w, 64), tiles_y = ceil_div(h, 64);
     const long long blocks = (long long)tiles_x * tiles_y * n;
     if (blocks > 0x7fffffffLL)
         return fail(RF_E_UNSUPPORTED, "rf_jbf_u8: batch too large for one launch");
-    auto kern = jbf_wide_kernel<GREP, TLW>;
+    auto kern = jbf_slab_kernel<GREP, TLW>;
     RF_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      kT64Lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(1024), kT64Lds, stream, joint, src, dst, h,
                        w, jcn, scn, t.radius, border, t.d_lut, nz, t.d_hw, t.d_swsym, t.sw_len,
-                       tiles_x, tiles_x * tiles_y, flags, crows);
+                       tiles_x, tiles_x * tiles_y, flags, crows, slab_rows);
     return RF_OK;
 }
 
@@ -2507,7 +2539,7 @@ extern "C" int rf_jbf_u8(const uint8_t *joint, const uint8_t *src, uint8_t *dst,
     // src; the clamp-free 8x table is next
     // tune 7 forces the 64x64 kernel, tune 1..6 the 64xTH kernel
     bool done = false;
-    if (!(flags & RF_JBF_FORCE_GENERIC) && t.r4 <= 72 && (tune == 0 || tune == 7)) {
+    if (!(flags & RF_JBF_FORCE_GENERIC) && t.r4 <= 132 && (tune == 0 || tune == 7)) {
         bool oob_ok = false;
         rc = lds_oob_reads_zero(t.device, &oob_ok);
         if (rc != RF_OK)
@@ -2554,25 +2586,35 @@ extern "C" int rf_jbf_u8(const uint8_t *joint, const uint8_t *src, uint8_t *dst,
                 RF_T64(8, 4, 176)
             }
 #undef RF_T64
-            // radius 53..72: row-band passes of the grey loop (the most rows per pass first, then the
-            // most LUT replicas: half the rows is half the lanes, fewer replicas a few bank conflicts)
-            if (!done && t.r4 > 52) {
-                const int tlw = t.r4 <= 68 ? 208 : 240;
-                int best_rows = 0, best_rep = 0;
-                for (int rep : {16, 8, 4}) {
-                    const int rows = wide_fits(t, nz, rep, tlw);
-                    if (rows > best_rows)
-                        best_rows = rows, best_rep = rep;
+            // radius 53..132: tap-row slabs (jbf_slab_kernel)
+            if (!done && t.r4 > 52 && t.r4 <= 132) {
+                const int tlw = t.r4 <= 68    ? 208
+                                : t.r4 <= 84  ? 240
+                                : t.r4 <= 100 ? 272
+                                : t.r4 <= 116 ? 304
+                                              : 336;
+                int crows = 0, slab = 0, rep = 0;
+                for (int g : {16, 8}) {
+                    int cr, sl;
+                    slab_fits(t, nz, g, tlw, &cr, &sl);
+                    if (cr > crows)
+                        crows = cr, slab = sl, rep = g;
                 }
-                if (best_rows > 0) {
-#define RF_WIDE(REP_, TLW_)                                                                       \
-    launch_wide<REP_, TLW_>(t, nz, best_rows, joint, src, dst, n, h, w, jcn_kernel, src_cn, border, \
+                if (crows > 0) {
+#define RF_SLAB(REP_, TLW_)                                                                       \
+    launch_slab<REP_, TLW_>(t, nz, crows, slab, joint, src, dst, n, h, w, jcn_kernel, src_cn, border, \
                             flags, stream)
                     if (tlw == 208)
-                        rc = best_rep == 16 ? RF_WIDE(16, 208) : best_rep == 8 ? RF_WIDE(8, 208) : RF_WIDE(4, 208);
+                        rc = rep == 16 ? RF_SLAB(16, 208) : RF_SLAB(8, 208);
+                    else if (tlw == 240)
+                        rc = rep == 16 ? RF_SLAB(16, 240) : RF_SLAB(8, 240);
+                    else if (tlw == 272)
+                        rc = rep == 16 ? RF_SLAB(16, 272) : RF_SLAB(8, 272);
+                    else if (tlw == 304)
+                        rc = rep == 16 ? RF_SLAB(16, 304) : RF_SLAB(8, 304);
                     else
-                        rc = best_rep == 16 ? RF_WIDE(16, 240) : best_rep == 8 ? RF_WIDE(8, 240) : RF_WIDE(4, 240);
-#undef RF_WIDE
+                        rc = rep == 16 ? RF_SLAB(16, 336) : RF_SLAB(8, 336);
+#undef RF_SLAB
                     if (rc != RF_OK)
                         return rc;
                     done = true;

@@ -191,7 +191,7 @@ def test_inline_asm_scalar_loads_are_not_touched_before_their_wait(disassembly):
     machine code of every kernel that streams this way, along every path of the control-flow graph."""
     checked = 0
     for name, insts in disassembly.items():
-        if "cnn_reflectance" not in name and "jbf_tile64" not in name and "jbf_wide" not in name:
+        if "cnn_reflectance" not in name and "jbf_tile64" not in name and "jbf_slab" not in name:
             continue
         checked += _smem_hazards(name, insts, _FLOW[name])
     assert checked > 20, "expected the weight-streaming scalar loads"

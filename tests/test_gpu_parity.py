@@ -95,7 +95,7 @@ def test_jbf_border_types_flags_and_generic_kernel(env):
     # very wide colour kernel: the LUT has no zero tail (exercises the untruncated table)
     want = co.joint_bilateral_filter(joint, src, -1, 400, 5)
     assert np.array_equal(rf.ops.joint_bilateral_u8(j, s, -1, 400, 5)[0].cpu().numpy(), want)
-    # radius 60: row-band kernel; radius 75: too large for any LDS tile -> the untiled kernel is picked
+    # radius 60 and 75: the slab kernel (round 6; radius 75 ran untiled before)
     want = co.joint_bilateral_filter(joint, src, -1, 20, 40)
     assert np.array_equal(rf.ops.joint_bilateral_u8(j, s, -1, 20, 40)[0].cpu().numpy(), want)
     want = co.joint_bilateral_filter(joint, src, -1, 20, 50)
@@ -107,10 +107,10 @@ def test_jbf_border_types_flags_and_generic_kernel(env):
 def test_jbf_wide_radius_tiles(env, ss, sc):
     """radius 42 / 52 / 36: the 176-texel row pitch (grey and colour tiles) and the pitch
     boundary; README.md:63 of the reference uses c15 s28.  Radius 54 / 60 / 64 / 68 (--sigma_spatial
-    is a free float, /root/reference/filter_reflectance.py:117-119): row-band passes of the grey
-    loop at pitch 208 (32-row passes; three passes per band for a colour src); radius 70 / 72: the same
-    at pitch 240 in 16-row passes; radius 74 (sigma 49): beyond the tiles, one thread per pixel.  Grey,
-    colour, 1-channel and mixed grey / colour tiles."""
+    is a free float, /root/reference/filter_reflectance.py:117-119): the slab kernel (round 6; tap rows
+    in slabs, the grey loop, three passes for a colour src) at pitch 208; radius 70 / 72 / 74: the same at
+    pitch 240 (radius 74 - sigma 49 - ran one thread per pixel until round 6).  Grey, colour, 1-channel
+    and mixed grey / colour tiles."""
     from tests import synth
     rf, co, torch = env
     joint = synth.flat_guide_u8(100, 150, seed=int(ss), cells=30)
@@ -136,8 +136,8 @@ def test_jbf_wide_radius_tiles(env, ss, sc):
 def test_jbf_every_radius_of_the_tiled_kernels(env):
     """Radius 1 .. 73 one by one (explicit diameter 2 r + 1): since round 5 a tap row starts at the even
     column below its half-width and runs whole groups of four, so every radius walks its own pattern of
-    row phases and group counts - through the 64x64 tiles (radius <= 52, three row pitches), the row-band
-    kernel (53 .. 72) and, at 73, the untiled one.  Grey src and 1-channel buffers (the loop of the
+    row phases and group counts - through the 64x64 tiles (radius <= 52, three row pitches) and the slab
+    kernel (53 .. 73: pitch 208 and 240).  Grey src and 1-channel buffers (the loop of the
     CNN -> BF(CNN,CNN) chain) at every radius, a colour src at every third."""
     from tests import synth
     rf, co, torch = env
@@ -160,7 +160,7 @@ def test_jbf_every_radius_of_the_tiled_kernels(env):
                                          (139, 22.0, 3), (145, 22.0, 4), (147, 9.0, 2)])
 def test_jbf_wide_diameter_with_any_sigma_and_border(env, d, ss, border):
     """The radius can also come from `d` (radius = d / 2 whatever sigma_spatial is): 54 / 60 / 64 / 68 / 69 /
-    72 on the row-band kernel and 73 on the one-thread-per-pixel kernel, under every border mode, on an
+    72 / 73 on the slab kernel, under every border mode, on an
     image smaller than the radius in one direction (multi-bounce reflection) and a ragged one."""
     from tests import synth
     rf, co, torch = env
@@ -175,7 +175,7 @@ def test_jbf_wide_diameter_with_any_sigma_and_border(env, d, ss, border):
 
 @pytest.mark.parametrize("sigma_space", [36.0, 40.0, 47.0])
 def test_jbf_wide_radius_against_the_untiled_kernel(env, sigma_space):
-    """Radius 54 / 60 / 70 (the row-band kernel, which has a single tap loop and no test switches of
+    """Radius 54 / 60 / 70 (the slab kernel, which has a single tap loop and no test switches of
     its own) against the one-thread-per-pixel kernel (RF_JBF_FORCE_GENERIC) - an independent code path
     on the same device - with a colour src (three passes per row band), a grey src and a
     single-channel joint, and against the oracle for the colour case."""
@@ -196,6 +196,41 @@ def test_jbf_wide_radius_against_the_untiled_kernel(env, sigma_space):
                                                  flags=rf._ffi.JBF_FORCE_GENERIC))
     want = co.joint_bilateral_filter(joint, colour, -1, 15.0, sigma_space)
     assert np.array_equal(rf.ops.joint_bilateral_u8(j, c, -1, 15.0, sigma_space)[0].cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("radius", [73, 76, 77, 90, 100, 101, 117, 132])
+def test_jbf_slab_radius_against_the_untiled_kernel_and_the_oracle(env, radius):
+    """Radius 73..132 (round 6: the tile kernel in tap-row slabs, accumulators carried in registers
+    from slab to slab; every row pitch 272 / 304 / 336 and both ends of each): a colour src, a grey
+    src, a single-channel joint, every border mode the filter takes, an image smaller than the
+    radius - against the one-thread-per-pixel kernel (RF_JBF_FORCE_GENERIC) and, for one case per
+    radius, against the oracle."""
+    from tests import synth
+    rf, co, torch = env
+    h, w = 100, 140
+    joint = synth.scene_u8(h, w, seed=radius)
+    colour = synth.scene_u8(h, w, seed=radius + 1)
+    grey = synth.reflectance_like_u8(h, w, seed=radius + 2)
+    j, c, g = _dev(torch, joint, colour, grey)
+    d = 2 * radius + 1
+    ss = radius / 2.5
+    for src in (c, g):
+        tiled = rf.ops.joint_bilateral_u8(j, src, d, 25.0, ss)
+        plain = rf.ops.joint_bilateral_u8(j, src, d, 25.0, ss, flags=rf._ffi.JBF_FORCE_GENERIC)
+        assert torch.equal(tiled, plain)
+    j1 = j[..., :1].contiguous()
+    assert torch.equal(rf.ops.joint_bilateral_u8(j1, g, d, 25.0, ss),
+                       rf.ops.joint_bilateral_u8(j1, g, d, 25.0, ss, flags=rf._ffi.JBF_FORCE_GENERIC))
+    for border in (rf._ffi.BORDER_REPLICATE, rf._ffi.BORDER_REFLECT, rf._ffi.BORDER_WRAP):
+        assert torch.equal(rf.ops.joint_bilateral_u8(j, g, d, 25.0, ss, border=border),
+                           rf.ops.joint_bilateral_u8(j, g, d, 25.0, ss, border=border,
+                                                     flags=rf._ffi.JBF_FORCE_GENERIC)), border
+    want = co.joint_bilateral_filter(joint, colour, d, 25.0, ss)
+    assert np.array_equal(rf.ops.joint_bilateral_u8(j, c, d, 25.0, ss)[0].cpu().numpy(), want)
+    small = j[:, :40, :50].contiguous()
+    assert torch.equal(rf.ops.joint_bilateral_u8(small, small.clone(), d, 25.0, ss),
+                       rf.ops.joint_bilateral_u8(small, small.clone(), d, 25.0, ss,
+                                                 flags=rf._ffi.JBF_FORCE_GENERIC))
 
 
 def test_jbf_same_buffer_takes_opencvs_bilateral_filter_route(env):

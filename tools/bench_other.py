@@ -85,7 +85,17 @@ def main():
                                         ("jbf_c20s36_untiled_colour", flatj[:1], colour_src[:1], 20.0, 36.0,
                                          _ffi.JBF_FORCE_GENERIC),
                                         ("jbf_c20s47_bands_grey", flatj[:8], grey[:8], 20.0, 47.0, 0),
-                                        ("jbf_c20s51_untiled_grey", flatj[:1], grey[:1], 20.0, 51.0, 0)):
+                                        # (round 6: radius 73..132 in tap-row slabs; "*_untiled_*" forces the
+                                        #  one-thread-per-pixel kernel they ran on before)
+                                        ("jbf_c20s51_slabs_grey", flatj[:4], grey[:4], 20.0, 51.0, 0),
+                                        ("jbf_c20s51_slabs_colour", flatj[:4], colour_src[:4], 20.0, 51.0, 0),
+                                        ("jbf_c20s51_untiled_grey", flatj[:1], grey[:1], 20.0, 51.0,
+                                         _ffi.JBF_FORCE_GENERIC),
+                                        ("jbf_c20s66_slabs_grey", flatj[:4], grey[:4], 20.0, 66.0, 0),
+                                        ("jbf_c20s88_slabs_grey", flatj[:4], grey[:4], 20.0, 88.0, 0),
+                                        ("jbf_c20s88_untiled_grey", flatj[:1], grey[:1], 20.0, 88.0,
+                                         _ffi.JBF_FORCE_GENERIC),
+                                        ("jbf_c20s90_untiled_grey", flatj[:1], grey[:1], 20.0, 90.0, 0)):
         radius = int(round(1.5 * ss))
         nb_ = joint.shape[0]
         d_ = dstj[:nb_]
