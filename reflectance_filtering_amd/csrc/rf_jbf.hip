@@ -1274,7 +1274,9 @@ __device__ __forceinline__ void jbf_tap_loop_grey4_la2(uint32_t lut_lane_addr,
 // 12 of them on the full pipe (v_and with the literal mask kept in a VGPR is not): 4 v_sad_u8,
 // 4 v_lshl_add_u32, 3 v_cvt_f32_ubyte*; hipcc emits the SADs and address computations as one
 // burst of nine, here each full-pipe instruction is followed by a simple one (v_mul/v_add).
-template <int LUTREP, int TLW>
+// SLAB: tap rows i_first .. i_last only, tile row of tap row i = ty + i + row_bias, sums ADDED to (see
+// jbf_tap_loop_grey4_la2).
+template <int LUTREP, int TLW, bool SLAB = false>
 __device__ __forceinline__ void jbf_tap_loop_rgb6(uint32_t lut_lane_addr,
                                                   const float *__restrict__ swsym,
                                                   uint32_t tile_lane_addr,
@@ -1282,8 +1284,11 @@ __device__ __forceinline__ void jbf_tap_loop_rgb6(uint32_t lut_lane_addr,
                                                   const uint32_t (&jc)[kPix], int ty, int radius,
                                                   int r4, int sw_len,
                                                   const int *__restrict__ hwtab,
-                                                  float (&sum)[kPix][3], float (&wsum)[kPix])
+                                                  float (&sum)[kPix][3], float (&wsum)[kPix],
+                                                  int i_first = 0, int i_last = 0, int row_bias = 0)
 {
+    const int i_lo = SLAB ? i_first : -radius, i_hi = SLAB ? i_last : radius;
+    const int bias = SLAB ? row_bias : radius;
     constexpr int Q4 = TLW / 4;
     constexpr int SHIFT = LUTREP == 32 ? 7 : LUTREP == 16 ? 6 : LUTREP == 8 ? 5 : 4;
     static_assert(LUTREP == 32 || LUTREP == 16 || LUTREP == 8 || LUTREP == 4, "LUT replicas");
@@ -1300,7 +1305,7 @@ __device__ __forceinline__ void jbf_tap_loop_rgb6(uint32_t lut_lane_addr,
         const int hws = (hw + 1) & ~1;
         const int ai = i < 0 ? -i : i;
         const int c0 = r4 - hws;  // first column, relative to the lane's quad origin
-        const uint32_t quad = (uint32_t)((ty + i + radius) * TLW + (c0 >> 2));
+        const uint32_t quad = (uint32_t)((ty + i + bias) * TLW + (c0 >> 2));
         const bool phase = ((c0 >> 1) & 1) != 0;
         const uint32_t q23 = quad + (phase ? 1u : 2u * Q4);  // columns 2, 3 of the row's first group
         const uint32_t q01 = quad + (phase ? 2u * Q4 : 0u);  // columns 0, 1 of the row's first group
@@ -1321,7 +1326,7 @@ __device__ __forceinline__ void jbf_tap_loop_rgb6(uint32_t lut_lane_addr,
     float gg[2][kPix];
     uint32_t ta, tb, ta2, tb2, wa_addr;
     int ngroups;
-    row_addr(-radius, ta, tb, ta2, tb2, wa_addr, ngroups);
+    row_addr(i_lo, ta, tb, ta2, tb2, wa_addr, ngroups);
     // prologue of the first tap row (later rows get theirs from the last group of the row before)
     asm volatile("ds_read_b32 %0, %4\n\t"
                  "ds_read_b32 %1, %4 offset:%6\n\t"
@@ -1434,10 +1439,10 @@ __device__ __forceinline__ void jbf_tap_loop_rgb6(uint32_t lut_lane_addr,
         asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=&s"(wn8) : "s"(wp_));                      \
     }
 
-    for (int i = -radius; i <= radius; i++) {
+    for (int i = i_lo; i <= i_hi; i++) {
         uint32_t ta_next, tb_next, ta2_next, tb2_next, wa_next;
         int ngroups_next;
-        row_addr(i < radius ? i + 1 : i, ta_next, tb_next, ta2_next, tb2_next, wa_next, ngroups_next);
+        row_addr(i < i_hi ? i + 1 : i, ta_next, tb_next, ta2_next, tb2_next, wa_next, ngroups_next);
         for (int gq = 0; gq < ngroups - 1; gq++) {
             float wv[8];
             wv[0] = ws8[0]; wv[1] = ws8[1]; wv[2] = ws8[2]; wv[3] = ws8[3];
@@ -2080,8 +2085,12 @@ __global__ __launch_bounds__(1024) void jbf_slab_kernel(
     const uint8_t *__restrict__ joint, const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
     int h, int w, int jcn, int scn, int radius, int border, const float *__restrict__ lut, int nz,
     const int *__restrict__ hwtab, const float *__restrict__ swsym, int sw_len, int tiles_x,
-    int tiles_per_img, int flags, int crows, int slab_rows)
+    int tiles_per_img, int flags, int crows_g, int slab_g, int crows_c, int slab_c)
 {
+    // crows_g / slab_g: rows per band and per slab with 4-byte texels (grey src, or a 3-channel src
+    // whose tile turns out grey); crows_c / slab_c with 6-byte texels (colour src, one pass: main
+    // plane {B,G,R joint, B src} + a plane of 2-byte texels {G src, R src}, jbf_tap_loop_rgb6);
+    // crows_c = 0: no room for the second plane - one grey pass per channel
     constexpr int NT = 1024, Q4 = TLW / 4, QW = 16;
     static_assert(TLW % 32 == 16, "row pitch keeps the rows of a half-wave on disjoint banks");
     extern __shared__ __align__(16) unsigned char smem[];
@@ -2103,13 +2112,33 @@ __global__ __launch_bounds__(1024) void jbf_slab_kernel(
         lut_g[i] = lut[i / GREP];
     const uint32_t lut_lane_addr = lds_addr(lut_g) + (uint32_t)(tid & (GREP - 1)) * 4u;
     const uint32_t tile_lane_addr = lds_addr(tile4) + (uint32_t)tx * 4u;
+    // 3-channel src: is every src texel the tile's 64 rows will ever stage grey (B = G = R)?  One scan
+    // of the src bytes of tile + halo up front (a texel is then used by thousands of taps): a grey tile
+    // - the reference filters the CNN's grey map as a 3-channel image - takes ONE pass of the grey loop
+    int all_grey = scn == 1;
+    if (scn == 3) {
+        int grey = 1;
+        const int rows_all = min(64, h - tile_y0) + 2 * radius;
+        for (int item = tid; item < rows_all * Q4; item += NT) {
+            const int ry = item / Q4, k = item - ry * Q4;
+            const int gy = border_interpolate(tile_y0 - radius + ry, h, border);
+            uint32_t jv[4], sv[4];
+            load_tile_quad(joint, src, img, gy, tile_x0 - r4 + 4 * k, w, jcn, scn, border, jv, sv);
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                grey &= (int)(((sv[u] ^ (sv[u] >> 8)) & 0xffffu) == 0u);
+        }
+        // (the same word in every lane; said so, or the slab bounds - scalar-load addresses - count as divergent)
+        all_grey = __builtin_amdgcn_readfirstlane(block_all2(grey, 1, flag_word) & 1);  // (barrier inside)
+    }
+    const bool rgb6 = !all_grey && crows_c > 0;
+    const int crows = rgb6 ? crows_c : crows_g, slab_rows = rgb6 ? slab_c : slab_g;
     const bool active = tid < QW * crows;
     for (int y0 = tile_y0; y0 < tile_y0 + 64 && y0 < h; y0 += crows) {
-        int all_grey = scn == 1;
-        for (int c = 0; c < scn; c++) {
+        for (int c = 0; c < (all_grey || rgb6 ? 1 : scn); c++) {
             // the lane's four centre pixels (their joint values; border arithmetic as in the tile)
             uint32_t jc[kPix];
-            float sum1[kPix][1], wsum[kPix];
+            float sum1[kPix][1], sum3[kPix][3], wsum[kPix];
             {
                 uint32_t jv[4], sv[4];
                 load_tile_quad(joint, src, img, min(y0 + ty, h - 1), tile_x0 + 4 * tx, w, jcn, scn, border,
@@ -2117,15 +2146,15 @@ __global__ __launch_bounds__(1024) void jbf_slab_kernel(
 #pragma unroll
                 for (int p = 0; p < kPix; p++) {
                     jc[p] = jv[p] & 0x00ffffffu;
-                    sum1[p][0] = 0.f;
+                    sum1[p][0] = sum3[p][0] = sum3[p][1] = sum3[p][2] = 0.f;
                     wsum[p] = 0.f;
                 }
             }
-            int grey = 1;
             for (int i0 = -radius; i0 <= radius; i0 += slab_rows) {
                 const int i1 = min(i0 + slab_rows - 1, radius);
                 const int tlh = crows + (i1 - i0);
-                __syncthreads();  // everyone is done with the previous contents of the tile (and flag)
+                uint16_t *plane_b = reinterpret_cast<uint16_t *>(tile4 + (size_t)tlh * TLW);
+                __syncthreads();  // everyone is done with the previous contents of the tile
                 for (int item = tid; item < tlh * Q4; item += NT) {
                     const int ry = item / Q4, k = item - ry * Q4;
                     const int gy = border_interpolate(y0 + i0 + ry, h, border);
@@ -2133,34 +2162,33 @@ __global__ __launch_bounds__(1024) void jbf_slab_kernel(
                     load_tile_quad(joint, src, img, gy, tile_x0 - r4 + 4 * k, w, jcn, scn, border, jv, sv);
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
-                        if (c == 0 && scn == 3)
-                            grey &= (int)(((sv[u] ^ (sv[u] >> 8)) & 0xffffu) == 0u);
                         tile4[ry * TLW + u * Q4 + k] = jv[u] | (((sv[u] >> (8 * c)) & 0xffu) << 24);
+                        if (rgb6)
+                            plane_b[ry * TLW + u * Q4 + k] = (uint16_t)(sv[u] >> 8);
                     }
                 }
                 __syncthreads();
-                if (active)
-                    jbf_tap_loop_grey4_la2<GREP, TLW, false, true>(lut_lane_addr, swsym, tile_lane_addr, jc,
-                                                                   ty, radius, r4, sw_len, hwtab, sum1, wsum,
-                                                                   i0, i1, -i0);
-            }
-            if (c == 0 && scn == 3) {
-                __syncthreads();
-                all_grey = block_all2(grey, 1, flag_word) & 1;  // (barrier inside)
-                __syncthreads();                                // everyone has read the word
-                if (tid == 0)
-                    *flag_word = 3;
+                if (active) {
+                    if (rgb6)
+                        jbf_tap_loop_rgb6<GREP, TLW, true>(lut_lane_addr, swsym, tile_lane_addr,
+                                                           lds_addr(plane_b) + (uint32_t)tx * 2u, jc, ty,
+                                                           radius, r4, sw_len, hwtab, sum3, wsum, i0, i1, -i0);
+                    else
+                        jbf_tap_loop_grey4_la2<GREP, TLW, false, true>(lut_lane_addr, swsym, tile_lane_addr,
+                                                                       jc, ty, radius, r4, sw_len, hwtab,
+                                                                       sum1, wsum, i0, i1, -i0);
+                }
             }
             if (active) {
-                if (scn == 1)
+                if (rgb6)
+                    store_quad<3, 3>(dst, img, y0 + ty, tile_x0 + 4 * tx, h, w, sum3, wsum, flags);
+                else if (scn == 1)
                     store_quad<1, 1>(dst, img, y0 + ty, tile_x0 + 4 * tx, h, w, sum1, wsum, flags);
                 else if (all_grey)
                     store_quad<1, 3>(dst, img, y0 + ty, tile_x0 + 4 * tx, h, w, sum1, wsum, flags);
                 else
                     store_quad_channel(dst, img, y0 + ty, tile_x0 + 4 * tx, h, w, c, sum1, wsum, flags);
             }
-            if (all_grey)
-                break;
         }
     }
 }
@@ -2168,12 +2196,14 @@ __global__ __launch_bounds__(1024) void jbf_slab_kernel(
 // rows per band and per slab of jbf_slab_kernel at row pitch tlw for a LUT replicated grep times
 // (crows = 0: does not fit): all 64 rows of the tile in one band - every lane busy - as long as a
 // slab is at least 24 rows, else 32, else 16
-void slab_fits(const JbfTables &t, int nz, int grep, int tlw, int *crows, int *slab_rows)
+// (texel_bytes: 4 for the grey-packed plane alone, 6 with the colour plane beside it)
+void slab_fits(const JbfTables &t, int nz, int grep, int tlw, int texel_bytes, int *crows, int *slab_rows)
 {
     *crows = *slab_rows = 0;
     if (2 * t.r4 + 64 + 8 > tlw)
         return;
-    const long long rows = ((long long)kT64Lds - 16 - (long long)nz * grep * 4) / ((long long)tlw * 4);
+    const long long rows =
+        ((long long)kT64Lds - 16 - (long long)nz * grep * 4) / ((long long)tlw * texel_bytes);
     for (int cr : {64, 32, 16}) {
         const long long sl = rows - cr + 1;
         if (sl >= (cr == 16 ? 8 : 24)) {
@@ -2185,9 +2215,9 @@ void slab_fits(const JbfTables &t, int nz, int grep, int tlw, int *crows, int *s
 }
 
 template <int GREP, int TLW>
-int launch_slab(const JbfTables &t, int nz, int crows, int slab_rows, const uint8_t *joint,
-                const uint8_t *src, uint8_t *dst, int n, int h, int w, int jcn, int scn, int border,
-                int flags, hipStream_t stream)
+int launch_slab(const JbfTables &t, int nz, int crows, int slab_rows, int crows_c, int slab_c,
+                const uint8_t *joint, const uint8_t *src, uint8_t *dst, int n, int h, int w, int jcn,
+                int scn, int border, int flags, hipStream_t stream)
 {
     const int tiles_x = ceil_div(w, 64), tiles_y = ceil_div(h, 64);
     const long long blocks = (long long)tiles_x * tiles_y * n;
@@ -2198,7 +2228,7 @@ int launch_slab(const JbfTables &t, int nz, int crows, int slab_rows, const uint
                                      kT64Lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(1024), kT64Lds, stream, joint, src, dst, h,
                        w, jcn, scn, t.radius, border, t.d_lut, nz, t.d_hw, t.d_swsym, t.sw_len,
-                       tiles_x, tiles_x * tiles_y, flags, crows, slab_rows);
+                       tiles_x, tiles_x * tiles_y, flags, crows, slab_rows, crows_c, slab_c);
     return RF_OK;
 }
 
@@ -2593,17 +2623,19 @@ extern "C" int rf_jbf_u8(const uint8_t *joint, const uint8_t *src, uint8_t *dst,
                                 : t.r4 <= 100 ? 272
                                 : t.r4 <= 116 ? 304
                                               : 336;
-                int crows = 0, slab = 0, rep = 0;
+                int crows = 0, slab = 0, rep = 0, crows_c = 0, slab_c = 0;
                 for (int g : {16, 8}) {
                     int cr, sl;
-                    slab_fits(t, nz, g, tlw, &cr, &sl);
+                    slab_fits(t, nz, g, tlw, 4, &cr, &sl);
                     if (cr > crows)
                         crows = cr, slab = sl, rep = g;
                 }
+                if (crows > 0 && src_cn == 3)  // a colour tile in one pass: 6-byte texels, same replicas
+                    slab_fits(t, nz, rep, tlw, 6, &crows_c, &slab_c);
                 if (crows > 0) {
 #define RF_SLAB(REP_, TLW_)                                                                       \
-    launch_slab<REP_, TLW_>(t, nz, crows, slab, joint, src, dst, n, h, w, jcn_kernel, src_cn, border, \
-                            flags, stream)
+    launch_slab<REP_, TLW_>(t, nz, crows, slab, crows_c, slab_c, joint, src, dst, n, h, w, jcn_kernel, \
+                            src_cn, border, flags, stream)
                     if (tlw == 208)
                         rc = rep == 16 ? RF_SLAB(16, 208) : RF_SLAB(8, 208);
                     else if (tlw == 240)

@@ -108,7 +108,7 @@ def test_jbf_wide_radius_tiles(env, ss, sc):
     """radius 42 / 52 / 36: the 176-texel row pitch (grey and colour tiles) and the pitch
     boundary; README.md:63 of the reference uses c15 s28.  Radius 54 / 60 / 64 / 68 (--sigma_spatial
     is a free float, /root/reference/filter_reflectance.py:117-119): the slab kernel (round 6; tap rows
-    in slabs, the grey loop, three passes for a colour src) at pitch 208; radius 70 / 72 / 74: the same at
+    in slabs; the grey loop, or one pass of the colour loop on 6-byte texels) at pitch 208; radius 70 / 72 / 74: the same at
     pitch 240 (radius 74 - sigma 49 - ran one thread per pixel until round 6).  Grey, colour, 1-channel
     and mixed grey / colour tiles."""
     from tests import synth
@@ -177,7 +177,7 @@ def test_jbf_wide_diameter_with_any_sigma_and_border(env, d, ss, border):
 def test_jbf_wide_radius_against_the_untiled_kernel(env, sigma_space):
     """Radius 54 / 60 / 70 (the slab kernel, which has a single tap loop and no test switches of
     its own) against the one-thread-per-pixel kernel (RF_JBF_FORCE_GENERIC) - an independent code path
-    on the same device - with a colour src (three passes per row band), a grey src and a
+    on the same device - with a colour src (the colour loop on 6-byte texels), a grey src and a
     single-channel joint, and against the oracle for the colour case."""
     from tests import synth
     rf, co, torch = env

@@ -70,9 +70,9 @@ def main():
     flatj = bench.flat_guide(scene)
     colour_src = scene.roll(shifts=(37, 91), dims=(1, 2)).contiguous()
     dstj = torch.empty_like(scene)
-    # (round 5: radius 53..72 run row-band passes of the grey tile loop; the *_generic_* tags keep their
-    #  round-4 names - they now time that form - and "*_untiled_*" is the one-thread-per-pixel kernel
-    #  they fell to before, forced through RF_JBF_FORCE_GENERIC on one image)
+    # (radius 53..132 run in tap-row slabs since round 6; the *_generic_* / *_bands_* tags keep their
+    #  round-4 / round-5 names - they now time that form - and "*_untiled_*" is the one-thread-per-pixel
+    #  kernel those radii fell to before, forced through RF_JBF_FORCE_GENERIC on one image)
     from reflectance_filtering_amd import _ffi
     for tag, joint, src, sc, ss, fl in (("jbf_c15s28_flat_colour", flatj, colour_src, 15.0, 28.0, 0),
                                         ("jbf_c15s28_flat_grey", flatj, grey, 15.0, 28.0, 0),
