@@ -10,7 +10,7 @@
  *                        default fuses stage 2 for every radius 1..96); identical bytes
  *   "jbf_compiler_loop"  joint bilateral: compiler-scheduled tap loop; identical bytes.  (This switch,
  *                        "jbf_lookahead1" and "jbf_stage_only" act on the 64x64-tile kernel, radius <= 52;
- *                        the slab kernel of radius 53..132 has one tap loop and ignores them - its
+ *                        the slab kernel of radius 53..468 has one tap loop and ignores them - its
  *                        independent check is RF_JBF_FORCE_GENERIC, tests/test_gpu_parity.py)
  *   "jbf_tile64_only"    joint bilateral: no strip tiles at the image remainder; identical bytes
  *   "jbf_tune"           joint bilateral: kernel-variant override 1..7 (tools/jbf_tune.py)

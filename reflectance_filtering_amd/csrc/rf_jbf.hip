@@ -11,8 +11,8 @@
 //   jbf_tile64_kernel  default for radius <= 52: one workgroup = 64x64 output tile (32x128,
 //                      16x256 or 128x32 for the image's remainder rows / columns), 1024 threads
 //                      (4 waves/SIMD), LDS-staged texel tile, LUT at the end of LDS.
-//   jbf_slab_kernel    radius 53..132: the same 64x64 outputs with the disk's tap rows taken in slabs
-//                      (row pitch 208 .. 336; the grey loop; a colour src one pass per channel).
+//   jbf_slab_kernel    radius 53..468: the same 64x64 outputs with the disk's tap rows taken in slabs
+//                      (row pitch 208 .. 1008; the grey loop; a colour src one pass per channel).
 //   jbf_tiled2_kernel  64 x TH tiles with 8-byte texels and a clamped/full LUT: used when the
 //                      LDS out-of-range probe fails, and by the tuning harness.
 //   jbf_generic_kernel untiled, any radius, global-memory gathers (fallback + cross-check).
@@ -40,6 +40,7 @@ constexpr int kTileW = 64;
 constexpr int kPix = 4;        // outputs per lane (horizontal)
 constexpr int kMaxLds = 160 * 1024;
 constexpr int kTlw2 = 144;     // tile row pitch in texels of jbf_tiled2_kernel (radius <= 36)
+constexpr int kJbfMaxTiledR4 = 468;  // radius (rounded up to 4) the slab kernel's widest row pitch (1008) holds
 // private flag bits above the public RF_JBF_* ones: the test / benchmark switches of
 // rf_debug_option() as the kernels see them
 constexpr int kJbfStageOnly = 0x1000, kJbfCompilerLoop = 0x2000, kJbfTile64Only = 0x4000;
@@ -1005,7 +1006,7 @@ __device__ __forceinline__ void jbf_tap_loop_grey4_la2(uint32_t lut_lane_addr,
     constexpr int Q4 = TLW / 4;
     constexpr int SHIFT = LUTREP == 32 ? 7 : LUTREP == 16 ? 6 : LUTREP == 8 ? 5 : 4;
     static_assert(LUTREP == 32 || LUTREP == 16 || LUTREP == 8 || LUTREP == 4, "LUT replicas");
-    static_assert(3 * Q4 + 1 <= 255, "ds_read2_b32 offsets are 8 bits");
+    static_assert(Q4 + 1 <= 255, "ds_read2_b32 offsets are 8 bits (the largest one here: Q4 + 1)");
     static_assert(TLW % 4 == 0, "column-interleaved planes");
     uint32_t mask = 0x00ffffffu;
     asm volatile("" : "+v"(mask));  // keep the mask in a VGPR (a literal operand is full-pipe)
@@ -2065,7 +2066,7 @@ int launch_tile64_rows(const JbfTables &t, int nz, int crows, const uint8_t *joi
 }
 
 // ------------------------------------------------------------------------------------------
-// Radius 53..132 (--sigma_spatial is a free float of the reference's tool,
+// Radius 53..468 (--sigma_spatial is a free float of the reference's tool,
 // /root/reference/filter_reflectance.py:117-119: sigma 36 -> radius 54, 47 -> 70, 66 -> 99, 88 -> 132):
 // the 64x64 tile with its halo no longer fits the LDS.  The workgroup covers its 64x64 outputs in bands of
 // `crows` rows (all 64 - every lane busy - wherever that leaves room for a slab of 24 rows) and takes
@@ -2074,8 +2075,8 @@ int launch_tile64_rows(const JbfTables &t, int nz, int crows, const uint8_t *joi
 // slab to slab (jbf_tap_loop_grey4_la2<.., SLAB>; the weights come through scalar loads, so the LDS
 // holds only tile and LUT), and every pixel's taps still arrive in row-major order - the bytes of
 // the one-pass kernels and of the oracle.  The row pitch (64 outputs + 2 r4 + 8 columns) is bounded
-// by the 8-bit offsets of the loop's ds_read2: 336 texels, r4 <= 132; beyond that the untiled kernel
-// remains.  A 3-channel src whose channels differ takes one pass per channel (the weights are
+// by the 8-bit offsets of the loop's ds_read2: 1008 texels, r4 <= 468 (pitches in steps of 32 up to 336,
+// coarser beyond: a wider pitch than needed only costs slab rows); beyond that the untiled kernel remains.  A 3-channel src whose channels differ takes one pass per channel (the weights are
 // formed three times).  Round 5's row-band kernel (radius 53..72: bands of 32 / 16 / 8 rows with the
 // whole halo staged, i.e. a half to an eighth of the lanes busy) is gone: slabs run 7.3 G taps/s at
 // every radius (0.95 of the radius-33 rate) where the bands ran 6.7 at radius 54, 3.7 at radius 70.
@@ -2569,7 +2570,7 @@ extern "C" int rf_jbf_u8(const uint8_t *joint, const uint8_t *src, uint8_t *dst,
     // src; the clamp-free 8x table is next
     // tune 7 forces the 64x64 kernel, tune 1..6 the 64xTH kernel
     bool done = false;
-    if (!(flags & RF_JBF_FORCE_GENERIC) && t.r4 <= 132 && (tune == 0 || tune == 7)) {
+    if (!(flags & RF_JBF_FORCE_GENERIC) && t.r4 <= kJbfMaxTiledR4 && (tune == 0 || tune == 7)) {
         bool oob_ok = false;
         rc = lds_oob_reads_zero(t.device, &oob_ok);
         if (rc != RF_OK)
@@ -2616,13 +2617,19 @@ extern "C" int rf_jbf_u8(const uint8_t *joint, const uint8_t *src, uint8_t *dst,
                 RF_T64(8, 4, 176)
             }
 #undef RF_T64
-            // radius 53..132: tap-row slabs (jbf_slab_kernel)
-            if (!done && t.r4 > 52 && t.r4 <= 132) {
+            // radius 53..468: tap-row slabs (jbf_slab_kernel); row pitches in steps of 32 up to 336,
+            // coarser beyond (a wider pitch than needed only costs slab rows)
+            if (!done && t.r4 > 52 && t.r4 <= kJbfMaxTiledR4) {
                 const int tlw = t.r4 <= 68    ? 208
                                 : t.r4 <= 84  ? 240
                                 : t.r4 <= 100 ? 272
                                 : t.r4 <= 116 ? 304
-                                              : 336;
+                                : t.r4 <= 132 ? 336
+                                : t.r4 <= 164 ? 400
+                                : t.r4 <= 212 ? 496
+                                : t.r4 <= 276 ? 624
+                                : t.r4 <= 372 ? 816
+                                              : 1008;
                 int crows = 0, slab = 0, rep = 0, crows_c = 0, slab_c = 0;
                 for (int g : {16, 8}) {
                     int cr, sl;
@@ -2644,8 +2651,18 @@ extern "C" int rf_jbf_u8(const uint8_t *joint, const uint8_t *src, uint8_t *dst,
                         rc = rep == 16 ? RF_SLAB(16, 272) : RF_SLAB(8, 272);
                     else if (tlw == 304)
                         rc = rep == 16 ? RF_SLAB(16, 304) : RF_SLAB(8, 304);
-                    else
+                    else if (tlw == 336)
                         rc = rep == 16 ? RF_SLAB(16, 336) : RF_SLAB(8, 336);
+                    else if (tlw == 400)
+                        rc = rep == 16 ? RF_SLAB(16, 400) : RF_SLAB(8, 400);
+                    else if (tlw == 496)
+                        rc = rep == 16 ? RF_SLAB(16, 496) : RF_SLAB(8, 496);
+                    else if (tlw == 624)
+                        rc = rep == 16 ? RF_SLAB(16, 624) : RF_SLAB(8, 624);
+                    else if (tlw == 816)
+                        rc = rep == 16 ? RF_SLAB(16, 816) : RF_SLAB(8, 816);
+                    else
+                        rc = rep == 16 ? RF_SLAB(16, 1008) : RF_SLAB(8, 1008);
 #undef RF_SLAB
                     if (rc != RF_OK)
                         return rc;

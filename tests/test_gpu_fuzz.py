@@ -92,7 +92,7 @@ def test_joint_bilateral_random_cases_match_the_oracle(env):
         jcn, scn = int(rng.choice([1, 3])), int(rng.choice([1, 3]))
         joint = _image(rng, h, w, jcn, int(rng.integers(0, 4)))
         src = _image(rng, h, w, scn, int(rng.integers(0, 3)))
-        # radius 33 42 8 18 51 2 38 46 | 54 60 64 70 76 99 130 (tap-row slabs) 140 (one thread per pixel)
+        # radius 33 42 8 18 51 2 38 46 | 54 60 64 70 76 99 130 140 (tap-row slabs)
         ss = float(rng.choice([22.0, 28.0, 5.0, 12.3, 34.0, 1.0, 25.0, 31.0, 36.0, 40.0, 42.9, 47.0, 50.5,
                                66.0, 86.7, 93.3]))
         sc = float(rng.choice([20.0, 15.0, 4.0, 60.0, 0.5]))

@@ -233,6 +233,34 @@ def test_jbf_slab_radius_against_the_untiled_kernel_and_the_oracle(env, radius):
                                                  flags=rf._ffi.JBF_FORCE_GENERIC))
 
 
+@pytest.mark.parametrize("radius", [133, 164, 165, 212, 213, 276, 277, 372, 373, 468, 469])
+def test_jbf_slab_radius_beyond_132(env, radius):
+    """Radius 133..468: the slab kernel at its coarser row pitches (400 / 496 / 624 / 816 / 1008), both
+    ends of each, and 469 (the untiled kernel): a colour src, a grey src and a 1-channel joint against
+    the one-thread-per-pixel kernel; the colour case against the oracle where the CPU gets there in
+    seconds."""
+    from tests import synth
+    rf, co, torch = env
+    h, w = 70, 90
+    joint = synth.scene_u8(h, w, seed=radius)
+    colour = synth.scene_u8(h, w, seed=radius + 1)
+    grey = synth.reflectance_like_u8(h, w, seed=radius + 2)
+    j, c, g = _dev(torch, joint, colour, grey)
+    d = 2 * radius + 1
+    ss = radius / 2.0
+    for src in (c, g):
+        tiled = rf.ops.joint_bilateral_u8(j, src, d, 30.0, ss)
+        plain = rf.ops.joint_bilateral_u8(j, src, d, 30.0, ss, flags=rf._ffi.JBF_FORCE_GENERIC)
+        assert torch.equal(tiled, plain)
+    j1 = j[..., :1].contiguous()
+    assert torch.equal(rf.ops.joint_bilateral_u8(j1, g, d, 30.0, ss, border=rf._ffi.BORDER_REFLECT),
+                       rf.ops.joint_bilateral_u8(j1, g, d, 30.0, ss, border=rf._ffi.BORDER_REFLECT,
+                                                 flags=rf._ffi.JBF_FORCE_GENERIC))
+    if radius <= 213:
+        want = co.joint_bilateral_filter(joint, colour, d, 30.0, ss)
+        assert np.array_equal(rf.ops.joint_bilateral_u8(j, c, d, 30.0, ss)[0].cpu().numpy(), want)
+
+
 def test_jbf_same_buffer_takes_opencvs_bilateral_filter_route(env):
     """cv2.ximgproc.jointBilateralFilter(a, a, ...) - one buffer as joint and src, or no joint - is
     routed by OpenCV to cv::bilateralFilter: for a 1-channel image the last step is a true division

@@ -95,7 +95,9 @@ def main():
                                         ("jbf_c20s88_slabs_grey", flatj[:4], grey[:4], 20.0, 88.0, 0),
                                         ("jbf_c20s88_untiled_grey", flatj[:1], grey[:1], 20.0, 88.0,
                                          _ffi.JBF_FORCE_GENERIC),
-                                        ("jbf_c20s90_untiled_grey", flatj[:1], grey[:1], 20.0, 90.0, 0)):
+                                        ("jbf_c20s133_slabs_grey", flatj[:2], grey[:2], 20.0, 133.0, 0),
+                                        ("jbf_c20s133_slabs_colour", flatj[:1], colour_src[:1], 20.0, 133.0, 0),
+                                        ("jbf_c20s300_slabs_grey", flatj[:1], grey[:1], 20.0, 300.0, 0)):
         radius = int(round(1.5 * ss))
         nb_ = joint.shape[0]
         d_ = dstj[:nb_]
