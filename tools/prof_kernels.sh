@@ -17,7 +17,7 @@ for f in glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n = r["Name"]
         if "rf::" in n:
-            short = n.split("(")[0].replace("void rf::(anonymous namespace)::", "").replace("void rf::", "")
+            short = n.replace("(anonymous namespace)::", "").replace("void ", "").replace("rf::", "").split("(")[0]
             print("%-44s calls %3s  total %8.2f ms  avg %7.3f ms" % (short, r["Calls"], int(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e6))
 PY
 cat $O/${TAG}_kernels.txt
