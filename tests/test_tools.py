@@ -61,6 +61,34 @@ def test_t2_report_with_a_stand_in_opencv(tmp_path, monkeypatch):
     assert all(c["frozen_vector_vs_opencv"]["max_abs"] <= 1 for c in doc["cases"])
 
 
+def test_t2_report_freezes_what_opencv_returned(tmp_path, monkeypatch):
+    """`--freeze`: a stand-in `cv2` that answers with the oracle; the file then holds one result per
+    filter case, bit for bit what the stand-in returned, the version, the build digest and the verdict
+    of the variant search - what tests/test_golden_filters.py compares oracle and HIP path with."""
+    from oracle import c_oracle as co
+    fake = types.ModuleType("cv2")
+    fake.__version__ = "0.0-freeze"
+    fake.error = RuntimeError
+    fake.getBuildInformation = lambda: "stand-in build"
+    fake.getNumThreads = lambda: 1
+    fake.ximgproc = types.SimpleNamespace(
+        jointBilateralFilter=lambda joint, src, d, sc, ss: co.joint_bilateral_filter(joint, src, d, sc, ss),
+        guidedFilter=lambda guide, src, radius, eps: co.guided_filter(guide, src, radius, eps))
+    monkeypatch.setitem(sys.modules, "cv2", fake)
+    out, npz = tmp_path / "t2.json", tmp_path / "opencv_vectors.npz"
+    assert _load("t2_report").main(["--out", str(out), "--no-gpu", "--freeze", str(npz)]) == 0
+    data = np.load(npz)
+    meta = json.loads(str(data["meta"]))
+    assert meta["opencv"] == "0.0-freeze" and meta["default_is_exact"] == {"gf": True, "jbf": True}
+    golden = np.load(os.path.join(ROOT, "tests", "golden", "filter_vectors.npz"))
+    with open(os.path.join(ROOT, "tests", "golden", "filter_vectors.json")) as fh:
+        cases = sorted(k for k, e in json.load(fh)["cases"].items() if e["kind"] in ("jbf", "gf"))
+    assert sorted(f[:-len("/opencv")] for f in data.files if f.endswith("/opencv")) == cases
+    for name in cases:      # the stand-in IS the oracle, so its bytes are the frozen vectors
+        assert np.array_equal(data[name + "/opencv"], golden[name + "/out"]), name
+    assert json.loads(out.read_text())["frozen_to"]
+
+
 def test_t2_report_identifies_a_non_default_variant(tmp_path, monkeypatch):
     """A stand-in `cv2` whose filters make two of the choices the oracle recalled differently (true
     division in the joint bilateral; FMA-contracted helpers and `+ eps` on the diagonal in the

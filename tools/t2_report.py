@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Pin the oracle on a real OpenCV in one command (tier T2).
 
-    python tools/t2_report.py [--out profiles/t2_opencv.json] [--no-gpu]
+    python tools/t2_report.py [--out profiles/t2_opencv.json] [--no-gpu] [--freeze]
 
 On any machine with `opencv-contrib` (`import cv2; cv2.ximgproc`) this runs the reference's exact
 calls (/root/reference/filter_reflectance.py:60-70)
@@ -24,6 +24,12 @@ runs every combination of an operator's switches on every case (`variant_search`
 combination(s) that reproduce OpenCV bit for bit on ALL cases of that operator - the default one
 pins the oracle as it stands, another one says exactly which recalled choice to flip - or, if none
 does, the closest ones with their flip rates.
+
+`--freeze [PATH]` (default tests/golden/opencv_vectors.npz) also keeps what OpenCV returned: per case
+the bytes of `cv2.ximgproc` on the frozen inputs, plus the OpenCV version, the digest of its build
+information and the oracle variant(s) identified per operator.  Once that file is committed,
+tests/test_golden_filters.py holds the oracle AND the HIP path to OpenCV's own bytes on every
+machine - with or without cv2 there (the vectors are data: inputs and expected outputs).
 
 Without OpenCV the tool says so, writes a report whose `opencv` field is null, and exits with
 code 3.  Nothing of the reference is needed to run it: inputs are the committed fixtures.
@@ -107,6 +113,9 @@ def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "t2_opencv.json"))
     ap.add_argument("--no-gpu", action="store_true")
+    ap.add_argument("--freeze", nargs="?", const=os.path.join(GOLDEN, "opencv_vectors.npz"), default=None,
+                    metavar="PATH", help="keep OpenCV's bytes for the F5-F7 inputs (default: "
+                                         "tests/golden/opencv_vectors.npz)")
     args = ap.parse_args(argv)
     with open(os.path.join(GOLDEN, "filter_vectors.json")) as fh:
         manifest = json.load(fh)["cases"]
@@ -138,6 +147,7 @@ def main(argv=None):
         report["threads"] = int(cv2.getNumThreads())
         report["hip_path"] = rf is not None
         worst = 0
+        frozen = {}
         by_kind = {"jbf": [], "gf": []}
         for name in sorted(manifest):
             entry = manifest[name]
@@ -153,6 +163,7 @@ def main(argv=None):
                 report["cases"].append(row)
                 continue
             want = want.reshape(vectors[name + "/out"].shape)
+            frozen[name + "/opencv"] = np.ascontiguousarray(want)
             by_kind[entry["kind"]].append((entry, a, b, want))
             row["oracle_vs_opencv"] = compare(oracle_result(co, entry, a, b).reshape(want.shape), want)
             row["frozen_vector_vs_opencv"] = compare(vectors[name + "/out"], want)
@@ -206,6 +217,16 @@ def main(argv=None):
                     np.asarray(rf.ximgproc.jointBilateralFilter(g1, g1, -1, 40.0, 4.0)).reshape(want.shape), want)
         except Exception as exc:                    # noqa: BLE001 - an extra
             report["same_buffer_route"] = {"error": repr(exc)}
+        if args.freeze and frozen:
+            meta = {"opencv": report["opencv"], "opencv_build_sha256": report["opencv_build_sha256"],
+                    "inputs": report["inputs"],
+                    "identified": {k: vs["identified"] for k, vs in report["variant_search"].items()},
+                    "default_is_exact": {k: vs["default_is_exact"]
+                                         for k, vs in report["variant_search"].items()}}
+            frozen["meta"] = np.array(json.dumps(meta, sort_keys=True))
+            np.savez_compressed(args.freeze, **frozen)
+            report["frozen_to"] = os.path.relpath(args.freeze, ROOT)
+            print("froze %d OpenCV results to %s" % (len(frozen) - 1, args.freeze))
         report["worst_max_abs"] = worst
         report["verdict"] = ("pinned: %d cases byte-identical to OpenCV %s" % (len(compared), cv2.__version__)
                              if compared and worst == 0 else
