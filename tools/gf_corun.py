@@ -34,6 +34,10 @@ def main():
     import reflectance_filtering_amd as rf
     from reflectance_filtering_amd import _ffi
     so = os.path.join(ROOT, "tools", "microbench", "corun_read.so")
+    if not os.path.exists(so):          # (built artefacts are not in the history)
+        import subprocess
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so,
+                               os.path.join(ROOT, "tools", "microbench", "corun_read.hip")])
     rd = ctypes.CDLL(so)
     rd.corun_read.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                               ctypes.c_void_p, ctypes.c_void_p]
