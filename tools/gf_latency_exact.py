@@ -1,5 +1,16 @@
-import sys, json
-sys.path.insert(0, "/root/repo")
+#!/usr/bin/env python
+"""Single-image latency of the guided filter with and without the exact-row stage 2 (round 6).
+
+    gpurun -- python tools/gf_latency_exact.py > gpurun_out/lat.json
+
+1 / 2 / 4 images at 256x256, 1920x1080 and 3840x2160, one pass at radius 45, grey (3-channel) and
+colour src: best of 10 event-timed calls, ms per call, debug option gf_exact = 0 / 1
+(profiles/r06_gf_exact.md, "Single images").
+"""
+import json
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
 import reflectance_filtering_amd as rf
 from reflectance_filtering_amd import _ffi
