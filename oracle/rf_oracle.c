@@ -603,7 +603,8 @@ static void rfo_box_mean_census(const float *src, float *dst, int h, int w, int 
  * (w a multiple of 16, w >= 16), per row:
  *   pass[y]    the sufficient test as the GPU evaluates it on one plane: mx16 = bits of the largest
  *              magnitude >> 15, mn16 = (smallest non-zero magnitude's (bits << 1) - 2) >> 16; passes
- *              if mx16 == 0 or max(mx16 >> 8, 1) - max(mn16 >> 8, 1) <= 29 - ceil(log2 ks)
+ *              if mx16 == 0 or max(mx16 >> 8, 1) - max(mn16 >> 8, 1) <= 29 - ceil(log2 ks) (never with
+ *              an infinity or a NaN in the row: exponent field 255)
  *   rounded[y] operations of RowSum<float,double>'s chain (rfo_box_mean's row pass) that rounded
  *   equal[y]   1 if the row sum at every column 16 b, rebuilt the GPU's way - the sums of the aligned
  *              16-column blocks as a xor-butterfly over their 16 values, then prefix of block b + q
@@ -639,7 +640,7 @@ void rfo_exact_rows_check(const float *src, int rows, int w, int r, int *pass, i
                 e1 = 1;
             if (e0 < 1)
                 e0 = 1;
-            pass[y] = (mx16 == 0) || (e1 - e0 <= lim);
+            pass[y] = (mx16 == 0) || (e1 != 255 && e1 - e0 <= lim); /* 255: an infinity or a NaN */
         }
         for (int x = 0; x < ew; x++)
             ext[x] = S0[rfo_border_interpolate(x - r, w, RFO_BORDER_REFLECT)];

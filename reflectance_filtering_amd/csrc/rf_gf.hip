@@ -596,15 +596,16 @@ __global__ __launch_bounds__(stage1_threads(SCN))
         RF_S1_STAMP(3);
         __syncthreads();
         RF_S1_STAMP(4);
-        // exact rows: largest magnitude (as a float) and smallest non-zero magnitude (as (bits << 1) - 2,
-        // which sends a zero to the top) of the row's alpha planes jointly and of its beta plane, per
-        // src channel, over this lane's columns
-        float xmx_a[SCN], xmx_b[SCN];
+        // exact rows: largest magnitude (its bit pattern: an infinity or a NaN then counts as the largest
+        // exponent there is and fails the row) and smallest non-zero magnitude (as (bits << 1) - 2, which
+        // sends a zero to the top) of the row's alpha planes jointly and of its beta plane, per src
+        // channel, over this lane's columns
+        uint32_t xmx_a[SCN], xmx_b[SCN];
         uint32_t xmn_a[SCN], xmn_b[SCN];
         if (EXACT) {
 #pragma unroll
             for (int sc = 0; sc < SCN; sc++) {
-                xmx_a[sc] = xmx_b[sc] = 0.f;
+                xmx_a[sc] = xmx_b[sc] = 0u;
                 xmn_a[sc] = xmn_b[sc] = 0xffffffffu;
             }
         }
@@ -650,8 +651,9 @@ __global__ __launch_bounds__(stage1_threads(SCN))
                 for (int sc = 0; sc < SCN; sc++) {
                     const float a0 = ab_px[4 * sc], a1 = ab_px[4 * sc + 1], a2 = ab_px[4 * sc + 2],
                                 bt = ab_px[4 * sc + 3];
-                    xmx_a[sc] = fmaxf(fmaxf(xmx_a[sc], fabsf(a0)), fmaxf(fabsf(a1), fabsf(a2)));
-                    xmx_b[sc] = fmaxf(xmx_b[sc], fabsf(bt));
+                    xmx_a[sc] = max(max(xmx_a[sc], __float_as_uint(a0) & 0x7fffffffu),
+                                    max(__float_as_uint(a1) & 0x7fffffffu, __float_as_uint(a2) & 0x7fffffffu));
+                    xmx_b[sc] = max(xmx_b[sc], __float_as_uint(bt) & 0x7fffffffu);
                     xmn_a[sc] = min(min(xmn_a[sc], (__float_as_uint(a0) << 1) - 2u),
                                     min((__float_as_uint(a1) << 1) - 2u, (__float_as_uint(a2) << 1) - 2u));
                     xmn_b[sc] = min(xmn_b[sc], (__float_as_uint(bt) << 1) - 2u);
@@ -679,8 +681,8 @@ __global__ __launch_bounds__(stage1_threads(SCN))
             // the largest, maximum of the inverted smallest), lanes 0 and 32 store
 #pragma unroll
             for (int sc = 0; sc < SCN; sc++) {
-                uint32_t wa = ((__float_as_uint(xmx_a[sc]) >> 15) << 16) | (0xffffu - (xmn_a[sc] >> 16));
-                uint32_t wb = ((__float_as_uint(xmx_b[sc]) >> 15) << 16) | (0xffffu - (xmn_b[sc] >> 16));
+                uint32_t wa = ((xmx_a[sc] >> 15) << 16) | (0xffffu - (xmn_a[sc] >> 16));
+                uint32_t wb = ((xmx_b[sc] >> 15) << 16) | (0xffffu - (xmn_b[sc] >> 16));
                 wa = swizzle_pkmax<swz_xor(1)>(wa);
                 wb = swizzle_pkmax<swz_xor(1)>(wb);
                 wa = swizzle_pkmax<swz_xor(2)>(wa);

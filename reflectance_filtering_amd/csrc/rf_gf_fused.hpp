@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void gf_exact_rows_kernel(const uint2 *__restr
         if (mx16 == 0)
             return false;  // an all-zero row
         const int emax = max(mx16 >> 8, 1), emin = max(mn16 >> 8, 1);
-        return emax - emin > limit;
+        return emax == 255 || emax - emin > limit;  // (255: an infinity or a NaN in the row)
     };
     if (fails(wa) || fails(wb)) {
         atomicOr(&rowmask[(size_t)ig * mask_words + (row >> 5)], 1u << (row & 31));

@@ -309,6 +309,14 @@ def test_exact_rows_sufficient_test_implies_exact_chain():
         passed += int(sel.sum())
         failed_and_rounded += int((bad[~sel] != 0).sum())
     assert total >= 100000 and passed > total // 4 and failed_and_rounded > 100
+    # a row with an infinity or a NaN never passes (its chain would carry the NaN to the row's end,
+    # a window sum only while the value is inside the window)
+    bad_rows = np.ones((3, 64), np.float32)
+    bad_rows[0, 5], bad_rows[1, 9], bad_rows[2, :] = np.inf, np.nan, np.inf
+    ok = np.ones(3, np.int32)
+    fn(bad_rows.ctypes.data_as(f32p), 3, 64, 7, ok.ctypes.data_as(i32p),
+       np.zeros(3, np.int32).ctypes.data_as(i32p), np.zeros(3, np.int32).ctypes.data_as(i32p))
+    assert not ok.any()
 
 
 def test_cnn_oracle_against_torch_cpu_conv():
