@@ -2074,11 +2074,12 @@ int launch_tile64_rows(const JbfTables &t, int nz, int crows, const uint8_t *joi
 // halo at a time, 4-byte texels {B,G,R joint, ONE src byte}, the accumulators stay in registers from
 // slab to slab (jbf_tap_loop_grey4_la2<.., SLAB>; the weights come through scalar loads, so the LDS
 // holds only tile and LUT), and every pixel's taps still arrive in row-major order - the bytes of
-// the one-pass kernels.  The row pitch (64 outputs + 2 r4 + 8 columns) is bounded
-// by the 8-bit offsets of the loop's ds_read2: 1008 texels, r4 <= 468 (pitches in steps of 32 up to 336,
-// coarser beyond: a wider pitch than needed only costs slab rows); beyond that the untiled kernel remains.  A 3-channel src whose channels differ takes ONE pass of the colour loop on
-// 6-byte texels (jbf_tap_loop_rgb6<.., SLAB>; one pass per channel of the grey loop only where the second
-// plane leaves no room for a slab); a scan of the tile's src bytes up front sends a grey 3-channel tile to
+// the one-pass kernels.  The row pitch (64 outputs + 2 r4 + 8 columns) is bounded by the 8-bit offsets
+// of the loop's ds_read2: 1008 texels, r4 <= 468 (pitches in steps of 32 up to 336, coarser beyond: a
+// wider pitch than needed only costs slab rows); beyond that the untiled kernel remains.  A 3-channel
+// src whose channels differ takes ONE pass of the colour loop on 6-byte texels
+// (jbf_tap_loop_rgb6<.., SLAB>; one pass per channel of the grey loop only where the second plane
+// leaves no room for a slab); a scan of the tile's src bytes up front sends a grey 3-channel tile to
 // the grey loop.  Round 5's row-band kernel (radius 53..72: bands of 32 / 16 / 8 rows with the
 // whole halo staged, i.e. a half to an eighth of the lanes busy) is gone: slabs run 7.3 G taps/s at
 // every radius (0.95 of the radius-33 rate) where the bands ran 6.7 at radius 54, 3.7 at radius 70.
