@@ -7,7 +7,7 @@
  * not meant to be flipped while other threads are inside the library, and all default to 0.
  *
  *   "gf_two_kernel"      guided filter: row-sum / column-sum kernel pair for every radius (the
- *                        default fuses stage 2 for every radius 1..96); identical bytes
+ *                        default fuses stage 2 for every radius 1..128); identical bytes
  *   "jbf_compiler_loop"  joint bilateral: compiler-scheduled tap loop; identical bytes.  (This switch,
  *                        "jbf_lookahead1" and "jbf_stage_only" act on the 64x64-tile kernel, radius <= 52;
  *                        the slab kernel of radius 53..468 has one tap loop and ignores them - its

@@ -16,10 +16,10 @@
 //            sum down the image starting 2r rows above the first output row.  Both are
 //            reproduced as sequential chains (one lane per row / per column), exposed to the
 //            GPU as parallelism over rows x planes x images, in two forms with identical bytes:
-//            radius 1..96: gf_rowstate_kernel<R> + gf_colwalk_kernel<R> (rf_gf_fused.hpp,
+//            radius 1..128: gf_rowstate_kernel<R> + gf_colwalk_kernel<R> (rf_gf_fused.hpp,
 //            instantiated per radius in rf_gf_fused_inst.hip) - the double row sums never reach
-//            HBM; radius 97..120 and 0: gf_rowsum_kernel + gf_colsum_apply_kernel, which write
-//            every row sum (8 B per pixel and plane) and read it twice; radius 121..4096: the
+//            HBM; radius 0 (and the switch gf_two_kernel): gf_rowsum_kernel + gf_colsum_apply_kernel, which write
+//            every row sum (8 B per pixel and plane) and read it twice; radius 129..4096: the
 //            float kernels of rf_gf_f32 on float copies of the images, each pass rounded to uint8
 //            (on 8-bit data their double window sums are the same exact integers).
 //
@@ -1097,6 +1097,8 @@ void gf_shutdown()
 // The per-radius launchers live in the rf_gf_fused_<part>.o units (Makefile: GF_PARTS = 8).
 GfFusedLaunch gf_fused_part_0(int), gf_fused_part_1(int), gf_fused_part_2(int), gf_fused_part_3(int),
     gf_fused_part_4(int), gf_fused_part_5(int), gf_fused_part_6(int), gf_fused_part_7(int);
+// ... and the radii above kGfFusedSmallMax in rf_gf_fused_L<part>.o (GF_LARGE_PARTS = 4)
+GfFusedLaunch gf_fused_large_0(int), gf_fused_large_1(int), gf_fused_large_2(int), gf_fused_large_3(int);
 
 GfFusedLaunch gf_fused_launcher(int radius)
 {
@@ -1105,6 +1107,10 @@ GfFusedLaunch gf_fused_launcher(int radius)
                                   gf_fused_part_4, gf_fused_part_5, gf_fused_part_6, gf_fused_part_7};
     if (radius < 1 || radius > kGfFusedMaxRadius)
         return nullptr;
+    if (radius > kGfFusedSmallMax) {
+        static const Part large[4] = {gf_fused_large_0, gf_fused_large_1, gf_fused_large_2, gf_fused_large_3};
+        return large[(radius - kGfFusedSmallMax - 1) % 4](radius);
+    }
     return parts[(radius - 1) % 8](radius);
 }
 
@@ -1149,8 +1155,8 @@ size_t gf_exact_extra(int np, int h, int w)
     return (((size_t)(np / 4) * ((size_t)h * (slots * 8 + 8) + 16)) + 255) & ~(size_t)255;
 }
 constexpr size_t kGfSyncBytes = 256;
-// radii above this run the float kernels (uint32 window sums: (2r+1)^2 * 255^2 < 2^32; strip width)
-constexpr int kGfMaxRadiusU8 = 120;
+// radii above this run the float kernels (uint32 window sums: (2r+1)^2 * 255^2 < 2^32)
+constexpr int kGfMaxRadiusU8 = 128;  // (2 * 128 + 1)^2 * 255^2 = 4,294,836,225 < 2^32: the last radius that fits
 // ... on float copies of guide, src and result + the float kernels' own planes and row sums
 constexpr size_t kGfF32Slack = 16;  // once per workspace: alignment of the float kernels' scratch
 size_t gf_per_img_via_f32(size_t npx, int src_cn)
@@ -1255,7 +1261,7 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
         // tool, /root/reference/filter_reflectance.py:67-70,118): the float kernels of rf_gf_f32 on
         // float copies of the images, every pass rounded to uint8 like convertTo(CV_8U).  On 8-bit
         // data the float path's double window sums are the same exact integers the 8-bit stage 1
-        // forms, so the bytes are what the 8-bit kernels would give (tested on either side of 120).
+        // forms, so the bytes are what the 8-bit kernels would give (tested on either side of 128).
         const size_t per_img_f = gf_per_img_via_f32(npx, src_cn);
         if (workspace_bytes < header + per_img_f + kGfF32Slack)
             return fail(RF_E_WORKSPACE, "rf_gf_u8: workspace %zu B < %zu B needed for one image at "
@@ -1296,7 +1302,7 @@ extern "C" int rf_gf_u8(const uint8_t *guide, const uint8_t *src, uint8_t *dst, 
     //   chained column walk (debug option "gf_chained", radius 45 and 52 only: no row-walk kernel, every block takes its row
     //       sums from its left neighbour; identical bytes, measured SLOWER - the stagger between
     //       neighbouring blocks costs the L2 sharing of their operand lines, profiles/r04_gf_chained.md)
-    //   row-sum / column-sum kernel pair (radius 0 and 97..120; debug option "gf_two_kernel")
+    //   row-sum / column-sum kernel pair (radius 0; debug option "gf_two_kernel")
     // (the fused kernels index planes with 32-bit element offsets: images below 2^28 pixels)
     const GfFusedLaunch fused_launch = gf_fused_launcher(radius);
     const bool can_fuse = !debug_get(kDbgGfTwoKernel) && fused_launch != nullptr &&

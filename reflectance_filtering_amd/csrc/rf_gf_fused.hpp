@@ -27,7 +27,8 @@
 
 namespace rf {
 
-constexpr int kGfFusedMaxRadius = 96;
+constexpr int kGfFusedMaxRadius = 128;  // (the 8-bit stage 1's uint32 window sums reach radius 128; round 6: the fused stage 2 follows it)
+constexpr int kGfFusedSmallMax = 96;    // radii above this one are compiled apart (rf_gf_fused_inst.hip, -DRF_GF_LARGE)
 constexpr int kSB = 16;     // columns per state block and per column-walk workgroup
 constexpr int kBRows = 64;  // rows per row-walk workgroup (one lane per row)
 constexpr int kGsFloatsPublic = 9;  // floats per pixel of the guide record kept by iterated calls

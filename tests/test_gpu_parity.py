@@ -1110,9 +1110,12 @@ def test_gf_guide_cache_switch(env):
     assert np.array_equal(got[0].cpu().numpy(), cur)
 
 
-@pytest.mark.parametrize("radius", [1, 2, 5, 7, 8, 13, 16, 17, 20, 30, 33, 47, 60, 64, 65, 77, 96, 97])
+@pytest.mark.parametrize("radius", [1, 2, 5, 7, 8, 13, 16, 17, 20, 30, 33, 47, 60, 64, 65, 77, 96, 97, 104,
+                                    111, 112, 113, 120, 121, 127, 128])
 def test_gf_fused_stage2_any_radius(env, radius):
-    """The fused stage 2 is instantiated for every radius 1..96 (97: the row-sum / column-sum pair):
+    """The fused stage 2 is instantiated for every radius 1..128 (round 6: 97..120 ran the row-sum /
+    column-sum pair, 121..128 the float kernels before; 128 is the last radius whose window sums fit
+    32 bits; the pair stays behind the switch gf_two_kernel and is compared below):
     sub-tiles of unequal height (47 = 16 + 16 + 15), one sub-tile per half period (radius < 16),
     the step-by-step row walk of radii below 8, one wave per SIMD above 64 - against the oracle
     (grey, colour and 1-channel src; two chained passes) and against the two-kernel form on a
@@ -1145,7 +1148,7 @@ def test_gf_fused_stage2_any_radius(env, radius):
 def test_gf_tiny_images_through_every_path(env):
     """Images far smaller than the window (multi-bounce borders, one column block, fewer rows than a
     sub-tile) through the fused path with the one-byte hand-off (grey 3-channel src, three passes),
-    the two-kernel pair (radius 100) and the float kernels (radius 150) - against the oracle."""
+    a large radius of the fused path (100; the two-kernel pair until round 6) and the float kernels (radius 150) - against the oracle."""
     from tests import synth
     rf, co, torch = env
     for (h, w) in ((1, 1), (1, 7), (5, 1), (3, 2), (17, 33)):
@@ -1261,7 +1264,7 @@ def test_gf_exact_rows_adversarial(env):
 
 def test_gf_radius_beyond_the_8bit_kernels(env):
     """int(sigma_spatial) is a free parameter of the reference's tool
-    (/root/reference/filter_reflectance.py:67-70,118): radii above 120 run the float kernels inside
+    (/root/reference/filter_reflectance.py:67-70,118): radii above 128 run the float kernels inside
     rf_gf_u8 and round every pass to uint8 - the oracle's bytes, through apply_filter, the batch
     operator (two passes, grey and colour and 1-channel src) and with a workspace for one image."""
     from tests import synth
@@ -1276,24 +1279,29 @@ def test_gf_radius_beyond_the_8bit_kernels(env):
     colour = synth.scene_u8(h, w, seed=7)
     g = torch.from_numpy(np.stack([joint, joint])).cuda()
     s = torch.from_numpy(np.stack([colour, image])).cuda()
-    for radius, eps in ((121, 7.0), (260, 3.0)):
+    for radius, eps in ((129, 7.0), (260, 3.0)):
         got2 = rf.ops.guided_filter_u8(g, s, radius, eps, iterations=2).cpu().numpy()
         for i, src in enumerate((colour, image)):
             want = co.guided_filter(joint, co.guided_filter(joint, src, radius, eps), radius, eps)
             assert np.array_equal(got2[i], want), (radius, i)
     one = torch.from_numpy(image[None, :, :, :1].copy()).cuda()
     lib = rf._ffi.load_library()
-    need1 = lib.rf_gf_workspace_bytes(1, h, w, 3, 1, 121)
+    need1 = lib.rf_gf_workspace_bytes(1, h, w, 3, 1, 129)
     ws = torch.empty(need1, dtype=torch.uint8, device="cuda")
     three = one.expand(3, -1, -1, -1).contiguous()
-    got3 = rf.ops.guided_filter_u8(g[:1].expand(3, -1, -1, -1).contiguous(), three, 121, 7.0,
+    got3 = rf.ops.guided_filter_u8(g[:1].expand(3, -1, -1, -1).contiguous(), three, 129, 7.0,
                                    workspace=ws).cpu().numpy()
-    want1 = co.guided_filter(joint, image[:, :, :1].copy(), 121, 7.0).reshape(got3[0].shape)
+    want1 = co.guided_filter(joint, image[:, :, :1].copy(), 129, 7.0).reshape(got3[0].shape)
     for i in range(3):
         assert np.array_equal(got3[i], want1)
-    # radius 120 (8-bit kernels) and 121 (float kernels) agree with the oracle on either side
-    a = rf.ops.guided_filter_u8(g[:1], s[1:], 120, 3.0).cpu().numpy()[0]
-    assert np.array_equal(a, co.guided_filter(joint, image, 120, 3.0))
+    # radius 128 (8-bit kernels: 257^2 x 255^2 is the last window sum below 2^32 - a white image makes
+    # every sum that large) and 129 (float kernels) agree with the oracle on either side
+    a = rf.ops.guided_filter_u8(g[:1], s[1:], 128, 3.0).cpu().numpy()[0]
+    assert np.array_equal(a, co.guided_filter(joint, image, 128, 3.0))
+    white = np.full((h, w, 3), 255, np.uint8)
+    wg = torch.from_numpy(white[None]).cuda()
+    assert np.array_equal(rf.ops.guided_filter_u8(wg, wg.clone(), 128, 3.0)[0].cpu().numpy(),
+                          co.guided_filter(white, white, 128, 3.0))
 
 
 @pytest.mark.parametrize("radius,eps", [(45, 3.0), (52, 7.0)])

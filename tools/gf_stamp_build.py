@@ -26,6 +26,8 @@ src = r'''
 namespace rf {
 #define RF_PART(K) GfFusedLaunch gf_fused_part_##K(int radius) { return radius == %d ? &gf_fused_launch<%d> : nullptr; }
 RF_PART(0) RF_PART(1) RF_PART(2) RF_PART(3) RF_PART(4) RF_PART(5) RF_PART(6) RF_PART(7)
+#define RF_LARGE(K) GfFusedLaunch gf_fused_large_##K(int) { return nullptr; }
+RF_LARGE(0) RF_LARGE(1) RF_LARGE(2) RF_LARGE(3)
 }
 extern "C" int rf_debug_gf_stamps(unsigned long long *out16)
 {
