@@ -1,3 +1,8 @@
+#!/usr/bin/env python
+"""Guided filter, one pass over 8 x 3840x2160 (grey CNN-style map as a 3-channel src), ms per call by
+radius - across the boundaries between the forms of stage 2 (round 6: fused up to 128, float kernels
+beyond):    gpurun -- python tools/gf_radius_time.py
+"""
 import sys, json
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
