@@ -51,7 +51,7 @@ def test_guided_filter_random_cases_match_the_oracle(env):
     cases = exact_cases = 0
     while time.time() < t_end or cases < 12:
         h, w = int(rng.integers(1, 150)), int(rng.integers(1, 220))
-        radius = int(rng.integers(1, 101)) if rng.random() < 0.8 else int(rng.choice([45, 52, 120]))
+        radius = int(rng.integers(1, 101)) if rng.random() < 0.8 else int(rng.choice([45, 52, 104, 120, 128, 129]))
         # (round 6) a sixth of the cases through the exact-row stage 2: its radii, a width that is a
         # multiple of 16 - white-noise guides and tiny eps make rows fail the test, constants pass it
         exact = rng.random() < 1.0 / 6.0
